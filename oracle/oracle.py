@@ -1,0 +1,233 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
+the product package gym_xarm_amd never does (tests/test_boundary.py greps for it).
+The model comes from gym_xarm_amd/model/xarm7_pd.json at run time, i.e. through a different
+path than the constexpr header the HIP kernels are compiled with.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+MODEL_JSON = os.path.join(ROOT, "gym_xarm_amd", "model", "xarm7_pd.json")
+LIB_PATH = os.path.join(HERE, "libxarm_oracle.so")
+
+MAXL, MAXD, NPAD = 12, 9, 4
+STATE_DIM, OBS_DIM, GOAL_DIM, ACT_DIM = 54, 24, 3, 4
+
+_d = C.c_double
+_i = C.c_int32
+
+
+class XoModel(C.Structure):
+    _fields_ = [
+        ("n_links", _i), ("parent", _i * MAXL), ("jtype", _i * MAXL),
+        ("eef_link", _i), ("hand_link", _i), ("finger_link", _i * 2),
+        ("org_p", (_d * 3) * MAXL), ("org_rpy", (_d * 3) * MAXL), ("axis", (_d * 3) * MAXL),
+        ("lower", _d * MAXL), ("upper", _d * MAXL), ("damping", _d * MAXL),
+        ("mass", _d * MAXL), ("com", (_d * 3) * MAXL), ("inertia", (_d * 6) * MAXL),
+        ("pad_radius", _d), ("pad_center_left", (_d * 3) * NPAD),
+        ("gravity", _d), ("contact_erp", _d), ("contact_margin", _d), ("warmstart", _d),
+        ("motor_kp", _d), ("motor_kd", _d), ("arm_motor_force", _d),
+        ("gear_erp", _d), ("gear_max_force", _d), ("global_erp", _d),
+        ("finger_contact_stiffness", _d), ("finger_contact_damping", _d), ("object_contact_damping", _d),
+        ("lin_damping", _d), ("ang_damping", _d), ("ik_lambda", _d), ("ik_residual", _d),
+        ("ik_max_dtheta", _d), ("limit_window", _d),
+        ("mu_object", _d), ("mu_table", _d), ("mu_finger", _d), ("mu_finger_grasp", _d),
+        ("num_iterations", _i), ("_pad0", _i),
+        ("table_half_x", _d), ("table_half_y", _d), ("table_top_z", _d),
+        ("time_step", _d), ("action_dt", _d), ("max_vel", _d), ("max_gripper_vel", _d),
+        ("pos_low", _d * 3), ("pos_high", _d * 3), ("goal_low", _d * 3), ("goal_high", _d * 3),
+        ("obj_low", _d * 2), ("obj_high", _d * 2),
+        ("gripper_low", _d), ("gripper_high", _d), ("height_offset", _d),
+        ("start_gripper_pos", _d * 3), ("reset_finger_target", _d),
+        ("finger_motor_force", _d), ("distance_threshold", _d),
+        ("obj_half", _d * 3), ("obj_mass", _d),
+        ("n_substeps", _i), ("reset_ticks", _i), ("max_episode_steps", _i), ("_pad1", _i),
+    ]
+
+
+class XoPnpCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("init_grasp_rate", _d),
+                ("goal_ground_rate", _d), ("goal_shape", _i), ("reward_type", _i)]
+
+
+JTYPE = {"fixed": 0, "revolute": 1, "prismatic": 2}
+REWARD_TYPES = {"sparse": 0, "dense_o2g": 1}
+GOAL_SHAPES = {"air": 0, "ground": 1}
+
+
+def load_model_json(path=MODEL_JSON):
+    with open(path) as f:
+        return json.load(f)
+
+
+def build_model(js=None):
+    js = js or load_model_json()
+    m = XoModel()
+    links = js["links"]
+    m.n_links = len(links)
+    for i, l in enumerate(links):
+        m.parent[i] = l["parent"]
+        m.jtype[i] = JTYPE[l["joint"]]
+        for k in range(3):
+            m.org_p[i][k] = l["origin_xyz"][k]
+            m.org_rpy[i][k] = l["origin_rpy"][k]
+            m.axis[i][k] = l["axis"][k]
+            m.com[i][k] = l["com"][k]
+        for k in range(6):
+            m.inertia[i][k] = l["inertia"][k]
+        m.lower[i], m.upper[i], m.damping[i], m.mass[i] = l["lower"], l["upper"], l["damping"], l["mass"]
+    m.eef_link, m.hand_link = js["eef_link"], js["hand_link"]
+    m.finger_link[0], m.finger_link[1] = js["finger_links"]
+    m.pad_radius = js["pads"]["radius"]
+    for j in range(NPAD):
+        for k in range(3):
+            m.pad_center_left[j][k] = js["pads"]["centers_left"][j][k]
+    for k, v in js["solver"].items():
+        if not k.startswith("_"):
+            setattr(m, k, v)
+    m.table_half_x, m.table_half_y, m.table_top_z = js["table"]["half_x"], js["table"]["half_y"], js["table"]["top_z"]
+    p = js["pick_and_place"]
+    for name in ("time_step", "action_dt", "max_vel", "max_gripper_vel", "gripper_low", "gripper_high",
+                 "height_offset", "reset_finger_target", "finger_motor_force", "distance_threshold",
+                 "obj_mass", "n_substeps", "reset_ticks", "max_episode_steps"):
+        setattr(m, name, p[name])
+    for name, n in (("pos_low", 3), ("pos_high", 3), ("goal_low", 3), ("goal_high", 3), ("obj_low", 2),
+                    ("obj_high", 2), ("start_gripper_pos", 3), ("obj_half", 3)):
+        arr = getattr(m, name)
+        for k in range(n):
+            arr[k] = p[name][k]
+    return m
+
+
+def build_lib(force=False):
+    src = os.path.join(HERE, "xarm_oracle.c")
+    hdr = os.path.join(HERE, "xarm_oracle.h")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B", "libxarm_oracle.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_lib()
+        L = C.CDLL(LIB_PATH)
+        dp, u8p = C.POINTER(_d), C.POINTER(C.c_uint8)
+        mp, cp = C.POINTER(XoModel), C.POINTER(XoPnpCfg)
+        L.xo_pnp_init.argtypes = [mp, cp, C.c_int64, dp]
+        L.xo_pnp_reset.argtypes = [mp, cp, C.c_int64, dp, u8p, dp, dp, dp]
+        L.xo_pnp_step.argtypes = [mp, cp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
+        L.xo_pnp_compute_reward.argtypes = [mp, _i, C.c_int64, dp, dp, dp]
+        L.xo_fk.argtypes = [mp, dp, dp, dp]
+        L.xo_ik.argtypes = [mp, dp, dp, _i, dp]
+        L.xo_mass_matrix_inv.argtypes = [mp, dp, dp]
+        L.xo_forward_dynamics.argtypes = [mp, dp, dp, dp, dp]
+        L.xo_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.xo_philox.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(_d))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class OraclePnP:
+    """Batched CPU PickAndPlace (num_obj = 1), float64, same call surface as the C-ABI."""
+
+    def __init__(self, num_envs, seed=0, env_id_offset=0, init_grasp_rate=0.0, goal_ground_rate=0.0,
+                 goal_shape="air", reward_type="sparse", model_json=None):
+        self.L = lib()
+        self.m = build_model(model_json)
+        self.cfg = XoPnpCfg(seed, env_id_offset, init_grasp_rate, goal_ground_rate,
+                            GOAL_SHAPES[goal_shape], REWARD_TYPES[reward_type])
+        self.E = int(num_envs)
+        self.state = np.zeros((self.E, STATE_DIM))
+        self.L.xo_pnp_init(self.m, self.cfg, self.E, _p(self.state))
+
+    def _bufs(self):
+        return (np.zeros((self.E, OBS_DIM)), np.zeros((self.E, GOAL_DIM)), np.zeros((self.E, GOAL_DIM)))
+
+    def reset(self, mask=None):
+        obs, ag, dg = self._bufs()
+        mk = None if mask is None else _u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xo_pnp_reset(self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
+        return obs, ag, dg
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.E, ACT_DIM)
+        obs, ag, dg = self._bufs()
+        rew = np.zeros(self.E)
+        done = np.zeros(self.E, dtype=np.uint8)
+        succ = np.zeros(self.E, dtype=np.uint8)
+        self.L.xo_pnp_step(self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg),
+                           _p(rew), _u8(done), _u8(succ))
+        return obs, ag, dg, rew, done, succ
+
+    def compute_reward(self, ag, g, reward_type=None):
+        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, 3)
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(ag.shape[0])
+        rt = self.cfg.reward_type if reward_type is None else REWARD_TYPES[reward_type]
+        self.L.xo_pnp_compute_reward(self.m, rt, ag.shape[0], _p(ag), _p(g), _p(out))
+        return out
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, s):
+        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, STATE_DIM)
+
+
+def fk(q, model=None):
+    m = model or build_model()
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    pos = np.zeros((m.n_links, 3))
+    rot = np.zeros((m.n_links, 9))
+    lib().xo_fk(m, _p(q), _p(pos), _p(rot))
+    return pos, rot.reshape(-1, 3, 3)
+
+
+def ik(q, target, max_iter=15, model=None):
+    m = model or build_model()
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    t = np.ascontiguousarray(target, dtype=np.float64)
+    out = np.zeros(MAXD)
+    lib().xo_ik(m, _p(q), _p(t), max_iter, _p(out))
+    return out
+
+
+def mass_matrix_inv(q, model=None):
+    m = model or build_model()
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    out = np.zeros((MAXD, MAXD))
+    lib().xo_mass_matrix_inv(m, _p(q), _p(out))
+    return out
+
+
+def forward_dynamics(q, qd, tau, model=None):
+    m = model or build_model()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau)]
+    out = np.zeros(MAXD)
+    lib().xo_forward_dynamics(m, _p(a[0]), _p(a[1]), _p(a[2]), _p(out))
+    return out
+
+
+def philox(seed, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().xo_philox(seed, c0, c1, c2, c3, out)
+    return [int(x) for x in out]

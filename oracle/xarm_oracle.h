@@ -1,0 +1,113 @@
+/*
+ * xarm_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+ *
+ * Plain-C restatement of the reference hot path `XarmPickAndPlace.step / reset /
+ * compute_reward` (/root/reference/gym_xarm/envs/xarm_pick_and_place.py:107-127,155-291)
+ * including the physics that the reference delegates to PyBullet
+ * (calculateInverseKinematics, setJointMotorControl2, createConstraint(JOINT_GEAR),
+ * getContactPoints, changeDynamics, stepSimulation — SURVEY.md §8a rows a3-a8).
+ *
+ * PARITY STATUS
+ *   - glue / observation layout / rewards / done: pinned by golden vectors generated from
+ *     the reference's own NumPy code (tests/golden/, tools/gen_golden.py) and by the URDF
+ *     known-answer FK values of SURVEY.md §8c.
+ *   - physics (everything PyBullet does): PARITY UNPINNED. pybullet 3.x (unpinned in the
+ *     reference's setup.py:17) is not installed and cannot be fetched; the algorithm below
+ *     restates Bullet's published multibody pipeline (Featherstone ABA in link coordinates,
+ *     per-row Jacobian + unit-impulse response, projected Gauss-Seidel with 50 iterations,
+ *     speculative contacts with ERP, velocity-level PD motors as solver rows, gear row,
+ *     joint-limit rows, semi-implicit Euler) with every constant listed in
+ *     gym_xarm_amd/model/xarm7_pd.json["solver"].
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (gym_xarm_amd) never links, imports or executes anything in oracle/.
+ */
+#ifndef XARM_ORACLE_H
+#define XARM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XO_MAXL 12 /* links  */
+#define XO_MAXD 9  /* joint dofs */
+#define XO_NPAD 4  /* pad spheres per finger */
+
+/* state / observation widths for PickAndPlace with one object (row-major [E, width]) */
+#define XO_STATE_DIM 54
+#define XO_OBS_DIM 24
+#define XO_GOAL_DIM 3
+#define XO_ACT_DIM 4
+
+typedef struct {
+    int32_t n_links;
+    int32_t parent[XO_MAXL];
+    int32_t jtype[XO_MAXL]; /* 0 fixed, 1 revolute, 2 prismatic */
+    int32_t eef_link, hand_link, finger_link[2];
+    double org_p[XO_MAXL][3];
+    double org_rpy[XO_MAXL][3];
+    double axis[XO_MAXL][3];
+    double lower[XO_MAXL], upper[XO_MAXL], damping[XO_MAXL];
+    double mass[XO_MAXL];
+    double com[XO_MAXL][3];
+    double inertia[XO_MAXL][6]; /* ixx ixy ixz iyy iyz izz about COM */
+    double pad_radius;
+    double pad_center_left[XO_NPAD][3];
+    /* solver */
+    double gravity, contact_erp, contact_margin, warmstart, motor_kp, motor_kd, arm_motor_force;
+    double gear_erp, gear_max_force, global_erp;
+    double finger_contact_stiffness, finger_contact_damping, object_contact_damping;
+    double lin_damping, ang_damping, ik_lambda, ik_residual, ik_max_dtheta, limit_window;
+    double mu_object, mu_table, mu_finger, mu_finger_grasp;
+    int32_t num_iterations;
+    int32_t _pad0;
+    /* table */
+    double table_half_x, table_half_y, table_top_z;
+    /* pick and place */
+    double time_step, action_dt, max_vel, max_gripper_vel;
+    double pos_low[3], pos_high[3], goal_low[3], goal_high[3], obj_low[2], obj_high[2];
+    double gripper_low, gripper_high, height_offset, start_gripper_pos[3], reset_finger_target;
+    double finger_motor_force, distance_threshold;
+    double obj_half[3], obj_mass;
+    int32_t n_substeps, reset_ticks, max_episode_steps, _pad1;
+} xo_model;
+
+typedef struct {
+    uint64_t seed;
+    int64_t env_id_offset;     /* global id of env 0 of this shard */
+    double init_grasp_rate;
+    double goal_ground_rate;
+    int32_t goal_shape;        /* 0 = 'air', 1 = 'ground' */
+    int32_t reward_type;       /* 0 = sparse, 1 = dense_o2g */
+} xo_pnp_cfg;
+
+/* state row layout (doubles): q[9] qd[9] box_pos[3] box_quat_xyzw[4] box_v[3] box_w[3] goal[3]
+ * lam_table[8] lam_pad[8] touch mu_grasp num_steps episode */
+
+int xo_state_dim(void);
+/* zero-pose arm, box at its episode-0 spawn, goal sampled; call xo_pnp_reset afterwards */
+int xo_pnp_init(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *state);
+/* reset envs with mask[e] != 0 (mask NULL = all); writes fresh obs rows for those envs */
+int xo_pnp_reset(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *state,
+                 const uint8_t *mask, double *obs, double *ag, double *dg);
+/* one env step for every env, no auto-reset */
+int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *state,
+                const double *actions, double *obs, double *ag, double *dg, double *reward,
+                uint8_t *done, uint8_t *success);
+/* batched reward restatement: xarm_pick_and_place.py:155-177 (sparse, dense_o2g) */
+int xo_pnp_compute_reward(const xo_model *m, int reward_type, int64_t n, const double *ag,
+                          const double *g, double *out);
+/* diagnostics used by tests */
+int xo_fk(const xo_model *m, const double *q, double *link_pos /*[n_links*3]*/,
+          double *link_rot /*[n_links*9]*/);
+int xo_ik(const xo_model *m, const double *q, const double *target, int max_iter, double *q_out);
+int xo_mass_matrix_inv(const xo_model *m, const double *q, double *minv /*[81]*/);
+int xo_forward_dynamics(const xo_model *m, const double *q, const double *qd, const double *tau,
+                        double *qdd);
+void xo_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -625,15 +625,19 @@ static void substep(const xo_model *m, real *st, const real *q_target, real dt) 
     /* --- rows, in the order the solver sweeps them */
     real *lam_t = st + S_LT, *lam_p = st + S_LP;
     int row_t_n[8], row_p_n[8];
-    /* (T) object corners against the table top */
+    /* (T) object corners against the table top; the manifold keeps at most 4 points
+     * (btPersistentManifold), here the first four active corners in index order */
+    int n_table = 0;
     for (int i = 0; i < 8; i++) {
         real rl[3] = {(i & 1) ? h[0] : -h[0], (i & 2) ? h[1] : -h[1], (i & 4) ? h[2] : -h[2]}, r[3], p[3];
         m3_vec(r, s.Rb, rl);
         v3_add(p, bp, r);
         real dist = p[2] - m->table_top_z;
-        int active = dist < m->contact_margin && fabs(p[0]) <= m->table_half_x && fabs(p[1]) <= m->table_half_y;
+        int active = dist < m->contact_margin && fabs(p[0]) <= m->table_half_x && fabs(p[1]) <= m->table_half_y &&
+                     n_table < 4;
         row_t_n[i] = -1;
         if (!active) { lam_t[i] = 0; continue; }
+        n_table++;
         real n[3] = {0, 0, 1};
         row_t_n[i] = add_contact(&s, -1, p, n, dist, dt, m->contact_erp, 0.0, m->mu_object * m->mu_table,
                                  m->warmstart * lam_t[i], bp);

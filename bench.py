@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec of XarmPDPickAndPlace-v0 (BASELINE.json `metric`).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one env step of EVERY environment of the job (one xarm_step call per rank), including
+the automatic resets of finished episodes.  Weak scaling: each rank owns `--envs-per-gpu` (default
+65 536, the configuration the metric is quoted on) independent environments, global env ids
+rank*E .. (rank+1)*E-1, no data-path collective.  Inputs are synthetic: a ring of
+64 pre-generated uniform[-1,1] action tensors resident in HBM, so the timed region contains no RNG
+and no host->device traffic.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 6.3 TB/s achievable)
+FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak, for the secondary (honest) bound
+ALGO_BYTES_PER_ENV_STEP = 452  # SURVEY.md 8(d), PnP N=1: state in+out, action in, obs/goals/reward/flags out
+
+
+def cpu_baseline(sample_envs_per_thread=128, steps=60):
+    """The CPU oracle (a restatement = kind "port"; PyBullet itself is absent) on the host cores:
+    every thread steps its own shard through ctypes (the GIL is released inside the C call)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    envs = [O.OraclePnP(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread) for k in range(cores)]
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(steps, cores, sample_envs_per_thread, 4))
+
+    def work(k):
+        envs[k].reset()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            envs[k].step(acts[s, k])
+        return time.perf_counter() - t0
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(work, range(cores)))
+        wall = time.perf_counter() - t0
+        # resets are outside the per-thread timers; redo the timed part alone for the rate
+        t0 = time.perf_counter()
+        list(ex.map(lambda k: [envs[k].step(acts[s, k]) for s in range(steps)], range(cores)))
+        wall_steps = time.perf_counter() - t0
+    n = cores * sample_envs_per_thread * steps
+    return {"value": n / wall_steps, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps of XarmPDPickAndPlace-v0 on the CPU oracle (float64, gcc -O2), %d threads, %.1f s"
+                      % (cores * sample_envs_per_thread, steps, cores, wall + wall_steps),
+            "reference": "unavailable (pybullet not importable)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gym_xarm_amd
+    from gym_xarm_amd import distributed as D
+
+    rank, local_rank, world = D.env_from_torchrun()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    E = args.envs_per_gpu
+    env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=0, env_id_offset=rank * E, device=dev,
+                            config=dict(GUI=False, num_obj=1, reward_type="sparse", init_grasp_rate=0.0,
+                                        goal_ground_rate=0.0, goal_shape="air"))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    ring = [torch.rand(E, 4, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
+    env.reset()
+    for i in range(args.warmup):
+        env.step(ring[i % 64])
+    torch.cuda.synchronize()
+    env.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_done = torch.zeros((), device=dev)
+    for i in range(args.steps):
+        obs, rew, done, info = env.step(ring[(args.warmup + i) % 64])
+        n_done += done.sum()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, device=dev)
+    total_envs = int(D.sum_over_ranks(E, device=dev))
+    kstep_ms_total, launches = env.timing_read()
+    kstep_ms = kstep_ms_total / max(launches, 1)
+    kstep_ms = D.max_over_ranks(kstep_ms, device=dev)
+    resets = D.sum_over_ranks(float(n_done.item()), device=dev)
+
+    if rank == 0:
+        value = total_envs * args.steps / dt
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP * E                 # one k_step launch processes E env steps
+        achieved = algo_bytes / (kstep_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_step_hbm_bytes_per_launch_%d" % E)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",
+                       "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": 15, "solver_iterations": 50,
+                       "auto_reset": True, "episodes_reset_in_window": int(resets), "parallelism": "env-shard x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_step",
+                         "kernel_avg_ms": kstep_ms, "kernel_launches": int(launches),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "fused step: HBM is touched once per env step, the kernel is fp32-VALU/latency bound (DESIGN.md)"},
+            "kernel_only_env_steps_per_sec_per_gpu": E / (kstep_ms * 1e-3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+"""gym_xarm_amd - MI355X-native batched Xarm7 manipulation environments.
+
+Registry mirroring /root/reference/gym_xarm/__init__.py:6-22 (`register(id, entry_point,
+max_episode_steps)`) plus the IDs the reference's README/test.py name (README.md:43-48, test.py:8).
+`make(id, num_envs=E, config=...)` returns the torch VecEnv; `make(id, config=...)` without
+num_envs returns the single-env object with the reference's numpy call surface.
+"""
+from . import _native  # noqa: F401
+from .vec_env import XarmPickAndPlaceVecEnv  # noqa: F401
+
+__version__ = "0.1.0"
+
+_REGISTRY = {}
+
+
+def register(id, entry_point, max_episode_steps, vec_entry_point=None):
+    _REGISTRY[id] = dict(entry_point=entry_point, max_episode_steps=max_episode_steps, vec_entry_point=vec_entry_point)
+
+
+def registered_ids():
+    return sorted(_REGISTRY)
+
+
+def spec(id):
+    if id not in _REGISTRY:
+        raise KeyError("No registered env with id: %s (known: %s)" % (id, ", ".join(registered_ids())))
+    return _REGISTRY[id]
+
+
+def _resolve(path):
+    mod, _, name = path.partition(":")
+    import importlib
+    return getattr(importlib.import_module(mod), name)
+
+
+def make(id, num_envs=None, config=None, **kwargs):
+    s = spec(id)
+    if num_envs is None:
+        return _resolve(s["entry_point"])(config, **kwargs)
+    return _resolve(s["vec_entry_point"])(num_envs, config=config, **kwargs)
+
+
+# registered in the reference (gym_xarm/__init__.py:18-22) and its BASELINE.json alias
+for _id in ("XarmPickAndPlace-v1", "XarmPDPickAndPlace-v0"):
+    register(_id, "gym_xarm_amd.envs:XarmPickAndPlace", 50, "gym_xarm_amd.vec_env:XarmPickAndPlaceVecEnv")

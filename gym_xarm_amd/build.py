@@ -1,0 +1,45 @@
+"""In-tree build of libxarm_hip.so (hipcc, gfx950 only)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libxarm_hip.so")
+SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def find_hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm); set HIPCC=/path/to/hipcc")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "xarm_hip.h")]
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    """Regenerate the model header and compile csrc/xarm_hip.hip -> csrc/libxarm_hip.so."""
+    gen = os.path.join(os.path.dirname(HERE), "tools", "gen_model_header.py")
+    if os.path.exists(gen):
+        subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
+    if not force and not stale():
+        return LIB
+    cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB, os.path.join(CSRC, "xarm_hip.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -32,10 +32,14 @@
 #define XARM_HD __device__ __forceinline__
 // wave-uniform "does any lane need this block" (64-wide ballot)
 #define XARM_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
+// Compiler-only fence.  The LDS columns are lane-private and never cross a barrier, so LLVM would
+// otherwise forward the staged values through registers (and then spill them to scratch).
+#define XARM_LDS_FENCE() asm volatile("" ::: "memory")
 #else
 #define XARM_HD inline
 // host build: always run the masked path so that the predication logic itself is tested
 #define XARM_ANY(p) (true)
+#define XARM_LDS_FENCE() ((void)0)
 #endif
 
 namespace xk {
@@ -468,6 +472,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         for (int r = 0; r < 9; r++)
 #pragma unroll
             for (int k = 0; k < 6; k++) lds[42 + r * 6 + k] = Tm[r][k];
+        XARM_LDS_FENCE();
     }
 
     // ---------------- object: frame, inverse inertia, unconstrained motion
@@ -522,7 +527,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             V3<T> r = b0 * ((i & 1) ? hx : -hx) + b1 * ((i & 2) ? hy : -hy) + b2 * ((i & 4) ? hz : -hz);
             V3<T> p = cb + r;
             const T dist = p.z - (T)xm::TABLE_TOP_Z;
-            const bool act = dist < (T)xm::CONTACT_MARGIN && xabs(p.x) <= (T)xm::TABLE_HALF_X &&
+            const bool act = dist < (T)xm::SOLVER_MARGIN && xabs(p.x) <= (T)xm::TABLE_HALF_X &&
                              xabs(p.y) <= (T)xm::TABLE_HALF_Y && cnt < NTS;
             const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist / dt : -dist / dt;
             const T l0 = (T)xm::WARMSTART * st.lam_t[i];
@@ -632,8 +637,10 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                 dist = -best - (T)xm::PAD_RADIUS;
                 pl = mk<T>(k == 0 ? s1 * hx : cl.x, k == 1 ? s1 * hy : cl.y, k == 2 ? s1 * hz : cl.z);
             }
-            const bool act = dist < (T)xm::CONTACT_MARGIN;
-            touch_f[fk] = touch_f[fk] || act;
+            // touch flag: inside Bullet's 0.02 contact-breaking margin (getContactPoints); solver rows
+            // only for points that can receive an impulse within one substep (dist < SOLVER_MARGIN)
+            const bool act = dist < (T)xm::SOLVER_MARGIN;
+            touch_f[fk] = touch_f[fk] || (dist < (T)xm::CONTACT_MARGIN);
             pad_any = pad_any || act;
             P.n = b0 * nl.x + b1 * nl.y + b2 * nl.z;
             P.p = cb + b0 * pl.x + b1 * pl.y + b2 * pl.z;
@@ -705,6 +712,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
     const T mu_p = (T)xm::MU_OBJECT * (st.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
 #pragma unroll 1
     for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+        XARM_LDS_FENCE(); // keep the S / T reads of this sweep as LDS reads inside the loop
         // (T) object / table points: n = +z, t1 = -y, t2 = +x
 #pragma unroll
         for (int s = 0; s < NTS; s++) {

@@ -1,0 +1,407 @@
+// xarm_hip.hip - gfx950 kernels and the C ABI (include/xarm_hip.h) of the batched
+// XarmPickAndPlace environment.
+//
+// Launch geometry: one thread per environment, one 64-lane wavefront per workgroup.  The fused
+// step keeps an environment's whole working set on chip for all 15 substeps x 50 solver sweeps:
+// ~400 VGPRs of per-env state/solver blocks (hence 1 wave per SIMD, __launch_bounds__(64)) plus
+// 96 floats per env of LDS (hand Jacobian S and T = M^-1 S^T), i.e. 24 KiB per workgroup.
+// 65 536 envs = 1024 workgroups = exactly 4 per CU on the 256 CUs; since workgroups are dealt
+// round-robin over the 8 XCDs and never communicate, no XCD-aware remap is needed.
+// HBM is touched once per env step: 54 state floats in, 54 out (structure-of-arrays, lane =
+// env, so every load/store is a fully coalesced 256-B wave access), 4 action floats in and the
+// 24+3+3+1 output floats + 2 flag bytes out (row-major at the API edge, 16-B vector stores).
+//
+// Episodes that end are compacted into a list (one wave-aggregated atomic per wavefront) and
+// re-initialised by k_reset, which runs the reference's 6 reset ticks only for those envs,
+// densely packed into wavefronts, instead of idling 63 lanes while one lane resets.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "../../include/xarm_hip.h"
+#include "xarm_core.h"
+
+namespace {
+
+constexpr int WG = 64;
+
+struct DevLds {
+    float *base;
+    __device__ __forceinline__ float &operator[](int i) const { return base[i * WG]; }
+};
+
+struct KParams {
+    float *state;      // [STATE_DIM][stride]
+    int64_t stride;    // padded env count
+    int64_t num_envs;
+    xk::EnvCfg cfg;
+    int auto_reset;
+};
+
+__device__ __forceinline__ void load_state(const KParams &P, int64_t e, xk::EnvState<float> &s) {
+    const float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { s.q[i] = S[(xk::S_Q + i) * n]; s.qd[i] = S[(xk::S_QD + i) * n]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        s.bp[i] = S[(xk::S_BP + i) * n]; s.bv[i] = S[(xk::S_BV + i) * n];
+        s.bw[i] = S[(xk::S_BW + i) * n]; s.goal[i] = S[(xk::S_GOAL + i) * n];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.bq[i] = S[(xk::S_BQ + i) * n];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s.lam_t[i] = S[(xk::S_LT + i) * n]; s.lam_p[i] = S[(xk::S_LP + i) * n]; }
+    s.touch = S[xk::S_TOUCH * n]; s.mug = S[xk::S_MUG * n]; s.steps = S[xk::S_STEPS * n]; s.episode = S[xk::S_EPISODE * n];
+}
+__device__ __forceinline__ void store_state(const KParams &P, int64_t e, const xk::EnvState<float> &s) {
+    float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { S[(xk::S_Q + i) * n] = s.q[i]; S[(xk::S_QD + i) * n] = s.qd[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        S[(xk::S_BP + i) * n] = s.bp[i]; S[(xk::S_BV + i) * n] = s.bv[i];
+        S[(xk::S_BW + i) * n] = s.bw[i]; S[(xk::S_GOAL + i) * n] = s.goal[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) S[(xk::S_BQ + i) * n] = s.bq[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { S[(xk::S_LT + i) * n] = s.lam_t[i]; S[(xk::S_LP + i) * n] = s.lam_p[i]; }
+    S[xk::S_TOUCH * n] = s.touch; S[xk::S_MUG * n] = s.mug; S[xk::S_STEPS * n] = s.steps; S[xk::S_EPISODE * n] = s.episode;
+}
+__device__ __forceinline__ void write_obs(const float (&obs)[xk::OBS_DIM], const xk::EnvState<float> &s, int64_t e,
+                                          float *obs_out, float *ag_out, float *dg_out) {
+    float4 *o = reinterpret_cast<float4 *>(obs_out + e * xk::OBS_DIM);
+#pragma unroll
+    for (int k = 0; k < xk::OBS_DIM / 4; k++) o[k] = make_float4(obs[4 * k], obs[4 * k + 1], obs[4 * k + 2], obs[4 * k + 3]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ag_out[e * 3 + k] = s.bp[k]; dg_out[e * 3 + k] = s.goal[k]; }
+}
+
+__global__ __launch_bounds__(WG) void k_init(KParams P) {
+    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e >= P.num_envs) return;
+    xk::EnvState<float> s;
+    xk::env_init<float>(P.cfg, e, s);
+    store_state(P, e, s);
+}
+
+// XarmPickAndPlace.step for every env; finished episodes are appended to done_list
+__global__ __launch_bounds__(WG) void k_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                             float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                             uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                             int *__restrict__ done_list, int *__restrict__ done_count,
+                                             int *__restrict__ stale_count) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e == 0 && stale_count) *stale_count = 0; // counter of the step before last, consumed by its k_reset
+    if (e >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xk::OBS_DIM], reward;
+    bool done, success;
+    xk::env_step<float, DevLds>(P.cfg, s, act, obs, reward, done, success, lds);
+    store_state(P, e, s);
+    write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = done ? 1 : 0;
+    succ_out[e] = success ? 1 : 0;
+    if (done && P.auto_reset) {
+        if (term_obs) {
+            float4 *o = reinterpret_cast<float4 *>(term_obs + e * xk::OBS_DIM);
+#pragma unroll
+            for (int k = 0; k < xk::OBS_DIM / 4; k++) o[k] = make_float4(obs[4 * k], obs[4 * k + 1], obs[4 * k + 2], obs[4 * k + 3]);
+        }
+        const int pos = atomicAdd(done_count, 1);
+        done_list[pos] = (int)e;
+    }
+}
+
+// XarmPickAndPlace.reset for the envs in list[0 .. *count): thread i handles env list[i]
+__global__ __launch_bounds__(WG) void k_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                              float *__restrict__ obs_out, float *__restrict__ ag_out,
+                                              float *__restrict__ dg_out) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (i >= n) return;
+    const int64_t e = list ? (int64_t)list[i] : i;
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e, s);
+    xk::env_reset<float, DevLds>(P.cfg, e, s, lds);
+    store_state(P, e, s);
+    if (obs_out) {
+        float obs[xk::OBS_DIM];
+        xk::get_obs(s, obs);
+        write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    }
+}
+
+// test hook: n internal substeps toward fixed joint targets (no action / IK / obs logic)
+__global__ __launch_bounds__(WG) void k_substeps(KParams P, const float *__restrict__ qt_in, int n) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e, s);
+    float qt[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) qt[k] = qt_in[e * 9 + k];
+    const float dt = (float)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+#pragma unroll 1
+    for (int k = 0; k < n; k++) xk::substep<float, DevLds>(s, qt, dt, lds);
+    store_state(P, e, s);
+}
+
+__global__ void k_compact_mask(const uint8_t *__restrict__ mask, int64_t n, int *__restrict__ list, int *__restrict__ count) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || !mask[e]) return;
+    const int pos = atomicAdd(count, 1);
+    list[pos] = (int)e;
+}
+
+// row-major [E, STATE_DIM] <-> structure-of-arrays [STATE_DIM][stride]
+__global__ void k_get_state(KParams P, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.num_envs * xk::STATE_DIM) return;
+    const int64_t e = i / xk::STATE_DIM, f = i % xk::STATE_DIM;
+    out[i] = P.state[f * P.stride + e];
+}
+__global__ void k_set_state(KParams P, const float *__restrict__ in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.num_envs * xk::STATE_DIM) return;
+    const int64_t e = i / xk::STATE_DIM, f = i % xk::STATE_DIM;
+    P.state[f * P.stride + e] = in[i];
+}
+
+__global__ void k_compute_reward(int reward_type, const float *__restrict__ ag, const float *__restrict__ g, int64_t n,
+                                 float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = ag[i * 3] - g[i * 3], dy = ag[i * 3 + 1] - g[i * 3 + 1], dz = ag[i * 3 + 2] - g[i * 3 + 2];
+    out[i] = xk::reward_of<float>(reward_type, sqrtf(dx * dx + dy * dy + dz * dz));
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------- C ABI
+struct xarm_handle {
+    xarm_config cfg;
+    KParams kp;
+    int *done_list;   // [E]
+    int *done_count;  // [2] ping-pong counters
+    int *mask_count;  // [1]
+    uint64_t step_index;
+    char err[512];
+    // timing
+    int timing;
+    static constexpr int NEV = 1024;
+    hipEvent_t ev0[NEV], ev1[NEV];
+    int ev_n;
+    double ev_ms;
+    int64_t ev_launches;
+    bool ev_created;
+};
+
+static char g_err[512] = "";
+
+static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
+    char *dst = h ? h->err : g_err;
+    snprintf(dst, 512, fmt, detail);
+    return code;
+}
+#define HIPCHK(h, call)                                                          \
+    do {                                                                         \
+        hipError_t _e = (call);                                                  \
+        if (_e != hipSuccess) return fail(h, XARM_E_HIP, #call ": %s", hipGetErrorString(_e)); \
+    } while (0)
+
+static void timing_flush(xarm_handle *h) {
+    for (int i = 0; i < h->ev_n; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]) == hipSuccess) {
+            h->ev_ms += ms;
+            h->ev_launches++;
+        }
+    }
+    h->ev_n = 0;
+}
+
+extern "C" {
+
+const char *xarm_version(void) { return "xarm_hip 0.1 (gfx950)"; }
+
+const char *xarm_last_error(const xarm_handle *h) { return h ? h->err : g_err; }
+
+int xarm_create(const xarm_config *cfg, xarm_handle **out) {
+    if (!cfg || !out) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: null argument");
+    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
+    if (cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
+    if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
+    if (cfg->reward_type != XARM_REWARD_SPARSE && cfg->reward_type != XARM_REWARD_DENSE_O2G)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
+    if (cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported goal_shape");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, XARM_E_NODEVICE, "%s", "xarm_create: no HIP device");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: bad device ordinal");
+    HIPCHK(nullptr, hipSetDevice(cfg->device));
+    xarm_handle *h = new (std::nothrow) xarm_handle();
+    if (!h) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: out of host memory");
+    memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    const int64_t E = cfg->num_envs, stride = (E + WG - 1) / WG * WG;
+    h->kp.stride = stride;
+    h->kp.num_envs = E;
+    h->kp.cfg.seed = cfg->seed;
+    h->kp.cfg.env_id_offset = cfg->env_id_offset;
+    h->kp.cfg.init_grasp_rate = cfg->init_grasp_rate;
+    h->kp.cfg.goal_ground_rate = cfg->goal_ground_rate;
+    h->kp.cfg.goal_shape = cfg->goal_shape;
+    h->kp.cfg.reward_type = cfg->reward_type;
+    h->kp.auto_reset = cfg->auto_reset;
+    hipError_t e1 = hipMalloc(&h->kp.state, sizeof(float) * xk::STATE_DIM * stride);
+    hipError_t e2 = hipMalloc(&h->done_list, sizeof(int) * stride);
+    hipError_t e3 = hipMalloc(&h->done_count, sizeof(int) * 2);
+    hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        fail(nullptr, XARM_E_HIP, "xarm_create: hipMalloc failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4))));
+        xarm_destroy(h);
+        return XARM_E_HIP;
+    }
+    hipMemset(h->kp.state, 0, sizeof(float) * xk::STATE_DIM * stride);
+    hipMemset(h->done_count, 0, sizeof(int) * 2);
+    hipMemset(h->mask_count, 0, sizeof(int));
+    k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
+    hipError_t e5 = hipDeviceSynchronize();
+    if (e5 != hipSuccess) {
+        fail(nullptr, XARM_E_HIP, "xarm_create: k_init: %s", hipGetErrorString(e5));
+        xarm_destroy(h);
+        return XARM_E_HIP;
+    }
+    *out = h;
+    return XARM_OK;
+}
+
+int xarm_destroy(xarm_handle *h) {
+    if (!h) return XARM_OK;
+    hipDeviceSynchronize();
+    if (h->ev_created)
+        for (int i = 0; i < xarm_handle::NEV; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
+    if (h->kp.state) hipFree(h->kp.state);
+    if (h->done_list) hipFree(h->done_list);
+    if (h->done_count) hipFree(h->done_count);
+    if (h->mask_count) hipFree(h->mask_count);
+    delete h;
+    return XARM_OK;
+}
+
+int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
+    if (!out) return XARM_E_INVALID;
+    (void)h;
+    out->obs_dim = xk::OBS_DIM;
+    out->goal_dim = xk::GOAL_DIM;
+    out->act_dim = xk::ACT_DIM;
+    out->state_dim = xk::STATE_DIM;
+    out->max_episode_steps = xm::PNP_MAX_EPISODE_STEPS;
+    out->n_substeps = xm::PNP_N_SUBSTEPS;
+    return XARM_OK;
+}
+
+int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *ag_dev, float *dg_dev, void *stream) {
+    if (!h) return XARM_E_INVALID;
+    if (obs_dev && (!ag_dev || !dg_dev)) return fail(h, XARM_E_INVALID, "%s", "xarm_reset: goal buffers required with obs");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(h->kp.stride / WG);
+    if (mask_dev) {
+        HIPCHK(h, hipMemsetAsync(h->mask_count, 0, sizeof(int), st));
+        k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
+        k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+    } else {
+        k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+    }
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *ag_dev, float *dg_dev, float *reward_dev,
+              uint8_t *done_dev, uint8_t *success_dev, float *terminal_obs_dev, void *stream) {
+    if (!h) return XARM_E_INVALID;
+    if (!actions_dev || !obs_dev || !ag_dev || !dg_dev || !reward_dev || !done_dev || !success_dev)
+        return fail(h, XARM_E_INVALID, "%s", "xarm_step: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(h->kp.stride / WG);
+    int *cnt = h->done_count + (h->step_index & 1), *stale = h->done_count + ((h->step_index + 1) & 1);
+    const bool timed = h->timing && h->ev_created;
+    if (timed && h->ev_n == xarm_handle::NEV) timing_flush(h);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
+    k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                            terminal_obs_dev, h->done_list, cnt, stale);
+    if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+    if (h->kp.auto_reset) k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+    h->step_index++;
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
+    if (!h) return XARM_E_INVALID;
+    if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
+    if (n == 0) return XARM_OK;
+    k_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->cfg.reward_type, ag_dev, g_dev, n, out_dev);
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_get_state(xarm_handle *h, float *state_dev, void *stream) {
+    if (!h || !state_dev) return XARM_E_INVALID;
+    const int64_t n = h->kp.num_envs * xk::STATE_DIM;
+    k_get_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
+    if (!h || !state_dev) return XARM_E_INVALID;
+    const int64_t n = h->kp.num_envs * xk::STATE_DIM;
+    k_set_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, void *stream) {
+    if (!h || !qtarget_dev || n < 0) return XARM_E_INVALID;
+    k_substeps<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, (hipStream_t)stream>>>(h->kp, qtarget_dev, n);
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_timing_enable(xarm_handle *h, int32_t enable) {
+    if (!h) return XARM_E_INVALID;
+    if (enable && !h->ev_created) {
+        for (int i = 0; i < xarm_handle::NEV; i++) {
+            HIPCHK(h, hipEventCreate(&h->ev0[i]));
+            HIPCHK(h, hipEventCreate(&h->ev1[i]));
+        }
+        h->ev_created = true;
+    }
+    if (enable) { h->ev_n = 0; h->ev_ms = 0; h->ev_launches = 0; }
+    h->timing = enable;
+    return XARM_OK;
+}
+int xarm_timing_read(xarm_handle *h, double *ms_total, int64_t *launches) {
+    if (!h || !ms_total || !launches) return XARM_E_INVALID;
+    timing_flush(h);
+    *ms_total = h->ev_ms;
+    *launches = h->ev_launches;
+    return XARM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,206 @@
+"""Batched XarmPickAndPlace on one MI355X: torch tensors in, torch tensors out, every env step is
+one call into libxarm_hip.so (include/xarm_hip.h).
+
+Mirrors the reference class `XarmPickAndPlace(gym.GoalEnv)`
+(/root/reference/gym_xarm/envs/xarm_pick_and_place.py:16) — same `config` keys (:17-20,68,164,
+261,272,276), same spaces (:95-100), same step/reset/compute_reward semantics — widened to E
+environments behind the Stable-Baselines3 VecEnv call surface the reference's train script drives
+(benchmark/train.py:74-79: make_vec_env -> VecNormalize -> A2C).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .spaces import Box, Dict
+
+CONFIG_DEFAULTS = {
+    # benchmark configuration, cf. xarm_pick_and_place.py:353-360
+    "GUI": False, "num_obj": 1, "reward_type": "sparse", "init_grasp_rate": 0.0,
+    "goal_ground_rate": 0.0, "goal_shape": "air",
+}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class XarmPickAndPlaceVecEnv:
+    """E independent XarmPickAndPlace environments stepped by hand-written HIP kernels."""
+
+    metadata = {"render.modes": ["rgb_array"], "video.frames_per_second": 30}
+
+    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True):
+        cfg = dict(CONFIG_DEFAULTS)
+        cfg.update(config or {})
+        self.config = cfg
+        if cfg.get("GUI"):
+            raise NotImplementedError("GUI / rendering is outside the HIP hot path (SURVEY.md 2 #20)")
+        if cfg["num_obj"] != 1:
+            raise NotImplementedError("this build supports num_obj == 1")
+        if cfg["reward_type"] not in _native.REWARD_TYPES:
+            # 'dense' needs contact state, 'dense_diff_o2g'/'incremental' raise in the reference itself
+            raise NotImplementedError("reward_type %r" % (cfg["reward_type"],))
+        if cfg["goal_shape"] not in _native.GOAL_SHAPES:
+            raise NotImplementedError("goal_shape %r" % (cfg["goal_shape"],))
+        if not torch.cuda.is_available():
+            raise _native.XarmNativeError("gym_xarm_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                          "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise _native.XarmNativeError("device must be a cuda (HIP) device, got %s" % self.device)
+        self._L = _native.load()
+        self.num_envs = int(num_envs)
+        self._seed = int(seed)
+        self._env_id_offset = int(env_id_offset)
+        self._auto_reset = bool(auto_reset)
+        self._h = C.c_void_p(0)
+        self._create()
+        d = _native.XarmDims()
+        _native.check(self._L, self._h, self._L.xarm_dims(self._h, C.byref(d)), "xarm_dims")
+        self.obs_dim, self.goal_dim, self.act_dim, self.state_dim = d.obs_dim, d.goal_dim, d.act_dim, d.state_dim
+        self._max_episode_steps = d.max_episode_steps
+        self.distance_threshold = 0.05
+        E, dev = self.num_envs, self.device
+        f32 = torch.float32
+        self._obs = torch.zeros(E, self.obs_dim, device=dev, dtype=f32)
+        self._ag = torch.zeros(E, self.goal_dim, device=dev, dtype=f32)
+        self._dg = torch.zeros(E, self.goal_dim, device=dev, dtype=f32)
+        self._rew = torch.zeros(E, device=dev, dtype=f32)
+        self._done = torch.zeros(E, device=dev, dtype=torch.uint8)
+        self._succ = torch.zeros(E, device=dev, dtype=torch.uint8)
+        self._term = torch.zeros(E, self.obs_dim, device=dev, dtype=f32)
+        self._actions = None
+        # single-env spaces, xarm_pick_and_place.py:95-100
+        self.action_space = Box(-1.0, 1.0, shape=(self.act_dim,), dtype=np.float32)
+        self.observation_space = Dict(dict(
+            desired_goal=Box(-np.inf, np.inf, shape=(self.goal_dim,), dtype=np.float32),
+            achieved_goal=Box(-np.inf, np.inf, shape=(self.goal_dim,), dtype=np.float32),
+            observation=Box(-np.inf, np.inf, shape=(self.obs_dim,), dtype=np.float32),
+        ))
+
+    # ------------------------------------------------------------------ native plumbing
+    def _create(self):
+        c = _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, _native.ENV_PICK_AND_PLACE,
+                               int(self.config["num_obj"]), _native.REWARD_TYPES[self.config["reward_type"]],
+                               _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
+                               float(self.config["goal_ground_rate"]), int(self._auto_reset),
+                               self.device.index if self.device.index is not None else torch.cuda.current_device())
+        h = C.c_void_p(0)
+        rc = self._L.xarm_create(C.byref(c), C.byref(h))
+        _native.check(self._L, None, rc, "xarm_create")
+        self._h = h
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _obs_dict(self):
+        return {"observation": self._obs, "achieved_goal": self._ag, "desired_goal": self._dg}
+
+    # ------------------------------------------------------------------ gym / VecEnv surface
+    def reset(self, mask=None):
+        """reset() of every env (or of the envs with mask != 0); returns the dict of [E, .] tensors."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.num_envs,):
+                raise ValueError("mask must have shape (%d,)" % self.num_envs)
+        rc = self._L.xarm_reset(self._h, _ptr(m), _ptr(self._obs), _ptr(self._ag), _ptr(self._dg), self._stream())
+        _native.check(self._L, self._h, rc, "xarm_reset")
+        return self._obs_dict()
+
+    def step_async(self, actions):
+        a = torch.as_tensor(actions, device=self.device, dtype=torch.float32)
+        # same contract as the reference's `assert action.shape == (4,)` (:200), per env
+        assert a.shape == (self.num_envs, self.act_dim), "action shape error"
+        self._actions = a.contiguous()
+
+    def step_wait(self):
+        rc = self._L.xarm_step(self._h, _ptr(self._actions), _ptr(self._obs), _ptr(self._ag), _ptr(self._dg),
+                               _ptr(self._rew), _ptr(self._done), _ptr(self._succ), _ptr(self._term), self._stream())
+        _native.check(self._L, self._h, rc, "xarm_step")
+        info = {"is_success": self._succ, "terminal_observation": self._term,
+                "TimeLimit.truncated": (self._done != 0) & (self._succ == 0)}
+        return self._obs_dict(), self._rew, self._done, info
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def compute_reward(self, achieved_goal, goal, info=None):
+        """Batched compute_reward (HER relabelling), xarm_pick_and_place.py:155-177."""
+        ag = torch.as_tensor(achieved_goal, device=self.device, dtype=torch.float32).contiguous()
+        g = torch.as_tensor(goal, device=self.device, dtype=torch.float32).contiguous()
+        assert ag.shape == g.shape and ag.shape[-1] == self.goal_dim
+        out = torch.empty(ag.shape[:-1], device=self.device, dtype=torch.float32)
+        n = out.numel()
+        rc = self._L.xarm_compute_reward(self._h, _ptr(ag), _ptr(g), n, _ptr(out), self._stream())
+        _native.check(self._L, self._h, rc, "xarm_compute_reward")
+        return out
+
+    def get_state(self):
+        s = torch.empty(self.num_envs, self.state_dim, device=self.device, dtype=torch.float32)
+        _native.check(self._L, self._h, self._L.xarm_get_state(self._h, _ptr(s), self._stream()), "xarm_get_state")
+        return s
+
+    def set_state(self, state):
+        s = torch.as_tensor(state, device=self.device, dtype=torch.float32).contiguous()
+        assert s.shape == (self.num_envs, self.state_dim)
+        _native.check(self._L, self._h, self._L.xarm_set_state(self._h, _ptr(s), self._stream()), "xarm_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # `s` may be a temporary
+
+    def debug_substeps(self, q_target, n):
+        """Test hook: n internal substeps toward joint targets [E,9] (include/xarm_hip.h)."""
+        qt = torch.as_tensor(q_target, device=self.device, dtype=torch.float32).contiguous()
+        assert qt.shape == (self.num_envs, 9)
+        _native.check(self._L, self._h, self._L.xarm_debug_substeps(self._h, _ptr(qt), int(n), self._stream()),
+                      "xarm_debug_substeps")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    @property
+    def goal(self):
+        return self._dg
+
+    def seed(self, seed=None):
+        """Re-key the per-env counter RNG: re-creates the native handle (state is re-initialised)."""
+        if seed is not None and int(seed) != self._seed:
+            self._seed = int(seed)
+            self._L.xarm_destroy(self._h)
+            self._create()
+        return [self._seed]
+
+    def env_method(self, name, *args, **kwargs):
+        return getattr(self, name)(*args, **kwargs)
+
+    def get_attr(self, name, indices=None):
+        n = self.num_envs if indices is None else len(indices)
+        return [getattr(self, name)] * n
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self, name, value)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def render(self, mode="rgb_array", **kw):
+        raise NotImplementedError("rendering is outside the HIP hot path (SURVEY.md 2 #20)")
+
+    def timing_enable(self, on=True):
+        _native.check(self._L, self._h, self._L.xarm_timing_enable(self._h, int(on)), "xarm_timing_enable")
+
+    def timing_read(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _native.check(self._L, self._h, self._L.xarm_timing_read(self._h, C.byref(ms), C.byref(n)), "xarm_timing_read")
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.xarm_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,106 @@
+/*
+ * xarm_hip.h - C ABI of libxarm_hip.so, the MI355X (gfx950) batched Xarm7 manipulation
+ * environment.  This is the drop-in boundary for the hot path of jc-bao/gym-xarm:
+ *
+ *   reference interface (Python, /root/reference/gym_xarm/envs/xarm_pick_and_place.py)
+ *     XarmPickAndPlace.__init__(config)            :17-103   -> xarm_create
+ *     XarmPickAndPlace.reset()                     :121-127  -> xarm_reset
+ *     XarmPickAndPlace.step(action)                :107-119  -> xarm_step
+ *     XarmPickAndPlace.compute_reward(ag, g, info) :155-177  -> xarm_compute_reward
+ *     XarmPickAndPlace.close / p.disconnect                  -> xarm_destroy
+ *   and the PyBullet C-API calls those methods make per step, which this
+ *   library replaces wholesale:  calculateInverseKinematics :207, setJointMotorControl2
+ *   :208-211, getContactPoints :212, changeDynamics :213-218, stepSimulation :111,
+ *   getLinkState/getJointStates/getBasePositionAndOrientation/getBaseVelocity :222-236.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative
+ *     XARM_E_* code and never throws; xarm_last_error() gives the message.
+ *   - all *_dev pointers are DEVICE pointers borrowed from the caller (e.g. torch tensors'
+ *     data_ptr()), row-major [num_envs, dim], float32 unless stated; they must stay valid
+ *     until the stream has executed the call.
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls are
+ *     asynchronous, the caller synchronises.
+ *   - one handle per GPU per process; a handle is not thread-safe.
+ */
+#ifndef XARM_HIP_H
+#define XARM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XARM_OK 0
+#define XARM_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define XARM_E_HIP (-2)       /* a HIP runtime call failed */
+#define XARM_E_NODEVICE (-3)  /* no HIP device available */
+
+#define XARM_ENV_PICK_AND_PLACE 0 /* XarmPickAndPlace-v1 / XarmPDPickAndPlace-v0 */
+
+#define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
+#define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */
+
+#define XARM_GOAL_AIR 0    /* goal_space.sample(), z -> ground w.p. goal_ground_rate  :272-280 */
+#define XARM_GOAL_GROUND 1 /* shared xy, z = 0.025 (2i+1)                             :282-286 */
+
+typedef struct xarm_config {
+    int64_t num_envs;       /* environments owned by this handle (this GPU's shard) */
+    int64_t env_id_offset;  /* global id of env 0 of the shard; the RNG is keyed by global id */
+    uint64_t seed;
+    int32_t env_kind;       /* XARM_ENV_* */
+    int32_t num_obj;        /* config['num_obj']; this build supports 1 */
+    int32_t reward_type;    /* XARM_REWARD_* (config['reward_type']) */
+    int32_t goal_shape;     /* XARM_GOAL_*   (config['goal_shape']) */
+    float init_grasp_rate;  /* config['init_grasp_rate'] */
+    float goal_ground_rate; /* config['goal_ground_rate'] */
+    int32_t auto_reset;     /* 1: envs that finish an episode in xarm_step are reset in the same call */
+    int32_t device;         /* HIP device ordinal */
+} xarm_config;
+
+typedef struct xarm_dims_t {
+    int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;
+} xarm_dims_t;
+
+typedef struct xarm_handle xarm_handle;
+
+int xarm_create(const xarm_config *cfg, xarm_handle **out);
+int xarm_destroy(xarm_handle *h);
+int xarm_dims(const xarm_handle *h, xarm_dims_t *out);
+
+/* reset(): mask_dev (uint8 [E], nullable = all envs) selects the environments to reset; the fresh
+ * observation rows of those envs are written, other rows are left untouched. */
+int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *achieved_goal_dev,
+               float *desired_goal_dev, void *stream);
+
+/* step(actions): actions [E,4]; outputs obs [E,24], achieved/desired goal [E,3], reward [E],
+ * done / is_success uint8 [E].  With auto_reset, rows of finished envs hold the first observation
+ * of the next episode and terminal_obs_dev (nullable, [E,24]) receives their last observation. */
+int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *achieved_goal_dev,
+              float *desired_goal_dev, float *reward_dev, uint8_t *done_dev, uint8_t *success_dev,
+              float *terminal_obs_dev, void *stream);
+
+/* compute_reward(achieved_goal, goal, info) over n rows of 3 floats (HER relabelling) */
+int xarm_compute_reward(xarm_handle *h, const float *achieved_goal_dev, const float *goal_dev, int64_t n,
+                        float *out_dev, void *stream);
+
+/* full simulator state, row-major [E, state_dim] (layout: gym_xarm_amd/csrc/xarm_core.h S_*);
+ * used for parity injection and snapshots */
+int xarm_get_state(xarm_handle *h, float *state_dev, void *stream);
+int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream);
+
+/* test hook: advance every env by n internal substeps (dt = 1/900 s) toward the joint targets
+ * qtarget_dev [E,9]; no action / IK / observation logic.  Used by the substep-level parity tests. */
+int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, void *stream);
+
+/* optional kernel timing: HIP events recorded around the step kernel on the caller's stream */
+int xarm_timing_enable(xarm_handle *h, int32_t enable);
+int xarm_timing_read(xarm_handle *h, double *step_kernel_ms_total, int64_t *launches);
+
+const char *xarm_last_error(const xarm_handle *h);
+const char *xarm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

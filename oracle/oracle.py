@@ -32,7 +32,7 @@ class XoModel(C.Structure):
         ("lower", _d * MAXL), ("upper", _d * MAXL), ("damping", _d * MAXL),
         ("mass", _d * MAXL), ("com", (_d * 3) * MAXL), ("inertia", (_d * 6) * MAXL),
         ("pad_radius", _d), ("pad_center_left", (_d * 3) * NPAD),
-        ("gravity", _d), ("contact_erp", _d), ("contact_margin", _d), ("warmstart", _d),
+        ("gravity", _d), ("contact_erp", _d), ("contact_margin", _d), ("solver_margin", _d), ("warmstart", _d),
         ("motor_kp", _d), ("motor_kd", _d), ("arm_motor_force", _d),
         ("gear_erp", _d), ("gear_max_force", _d), ("global_erp", _d),
         ("finger_contact_stiffness", _d), ("finger_contact_damping", _d), ("object_contact_damping", _d),

@@ -1,0 +1,69 @@
+"""Parity helpers (TEST INFRASTRUCTURE ONLY): conditioning-aware comparison of a float32
+implementation against the float64 oracle.
+
+Rigid contact dynamics with discrete collision features is not uniformly well conditioned: in
+states with deep inter-penetration (e.g. the object spawned inside the fingers after a reset,
+xarm_pick_and_place.py:262-265) a 1e-7 perturbation of the input state changes the state after one
+env step by O(0.1) even in float64.  A fixed tolerance is therefore wrong in both directions.
+The check used everywhere is
+        |x_f32 - x_oracle|  <=  atol + rtol |x_oracle| + K * sens
+where sens is the oracle's own sensitivity: the change of its output when its input state is
+perturbed by +-eps (eps = 1e-6, a few float32 ulps), measured per env.  In addition a quantile
+bound keeps the check from being vacuous: at least `frac_tight` of the envs must meet the plain
+atol/rtol bound with no sensitivity allowance.
+"""
+import numpy as np
+
+CONT = slice(0, 31)    # q, qd, box pose and velocities
+LAM = slice(34, 50)    # warm-start impulses
+ATOL, RTOL, K_SENS, EPS = 5e-4, 2e-4, 300.0, 1e-6
+# A sensitivity above this means the 1e-6 input perturbation was amplified > 5e4 times within one env
+# step: the transition sits on a discontinuity of the contact geometry (which box face a buried pad
+# sphere is pushed out of, which four corners form the table manifold, btPlaneSpace1's branch).
+# Two float64 implementations that agree to 1e-14 per substep disagree by O(1) there, so such envs
+# are exempt from the value comparison (their count is bounded instead).
+SENS_EXEMPT = 0.05
+
+
+def perturb(state, rng, eps=EPS):
+    s = np.array(state, dtype=np.float64, copy=True)
+    s[:, CONT] += rng.uniform(-eps, eps, size=s[:, CONT].shape)
+    q = s[:, 21:25]
+    s[:, 21:25] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return s
+
+
+def oracle_step_with_sens(ora, state, actions, n_perturb=2, seed=0):
+    """Returns (next_state, obs, ag, dg, rew, done, succ, sens[E]) of the oracle from `state`."""
+    rng = np.random.default_rng(seed)
+    ora.set_state(state)
+    out = ora.step(actions)
+    nxt = ora.get_state()
+    sens = np.zeros(state.shape[0])
+    for _ in range(n_perturb):
+        ora.set_state(perturb(state, rng))
+        ora.step(actions)
+        sens = np.maximum(sens, np.abs(ora.get_state()[:, CONT] - nxt[:, CONT]).max(axis=1))
+    ora.set_state(nxt)
+    return (nxt,) + tuple(out) + (sens,)
+
+
+def compare(x, ref, sens, atol=ATOL, rtol=RTOL, k=K_SENS, frac_tight=0.85, max_exempt=0.15, what="state"):
+    """x, ref: [E, n]; sens: [E].  Raises AssertionError with a report, returns stats dict."""
+    x = np.asarray(x, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(x - ref)
+    assert np.isfinite(x).all(), "%s: non-finite values" % what
+    bound_tight = atol + rtol * np.abs(ref)
+    tight = (err <= bound_tight).all(axis=1)
+    exempt = sens > SENS_EXEMPT
+    ok = (err <= bound_tight + k * sens[:, None]).all(axis=1) | exempt
+    stats = dict(max_err=float(err[~exempt].max()) if (~exempt).any() else 0.0,
+                 median_env_err=float(np.median(err.max(axis=1))),
+                 frac_tight=float(tight.mean()), frac_ok=float(ok.mean()), frac_exempt=float(exempt.mean()),
+                 max_sens=float(sens.max()))
+    if not ok.all() or tight.mean() < frac_tight or exempt.mean() > max_exempt:
+        bad = np.where(~ok)[0][:5]
+        raise AssertionError("%s parity failed: %s ; offending envs %s err %s sens %s" % (
+            what, stats, bad.tolist(), err[bad].max(axis=1).tolist(), sens[bad].tolist()))
+    return stats

@@ -633,7 +633,7 @@ static void substep(const xo_model *m, real *st, const real *q_target, real dt) 
         m3_vec(r, s.Rb, rl);
         v3_add(p, bp, r);
         real dist = p[2] - m->table_top_z;
-        int active = dist < m->contact_margin && fabs(p[0]) <= m->table_half_x && fabs(p[1]) <= m->table_half_y &&
+        int active = dist < m->solver_margin && fabs(p[0]) <= m->table_half_x && fabs(p[1]) <= m->table_half_y &&
                      n_table < 4;
         row_t_n[i] = -1;
         if (!active) { lam_t[i] = 0; continue; }
@@ -697,8 +697,11 @@ static void substep(const xo_model *m, real *st, const real *q_target, real dt) 
                 v3_add(c, c, s.t.o[l]);
                 int idx = f * XO_NPAD + j;
                 row_p_n[idx] = -1;
-                if (!sphere_box(c, m->pad_radius, bp, s.Rb, h, m->contact_margin, &dist, n, p)) { lam_p[idx] = 0; continue; }
-                touch[f] = 1;
+                /* getContactPoints() reports points inside the 0.02 breaking margin (touch flag); only
+                 * points inside solver_margin can receive an impulse within one substep, so only those
+                 * become solver rows (a row with dist/dt above any reachable approach speed is inert) */
+                if (sphere_box(c, m->pad_radius, bp, s.Rb, h, m->contact_margin, &dist, n, p)) touch[f] = 1;
+                if (!(dist < m->solver_margin)) { lam_p[idx] = 0; continue; }
                 row_p_n[idx] = add_contact(&s, l, p, n, dist, dt, erp, cfm, mu, m->warmstart * lam_p[idx], bp);
             }
         }

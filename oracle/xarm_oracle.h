@@ -55,7 +55,7 @@ typedef struct {
     double pad_radius;
     double pad_center_left[XO_NPAD][3];
     /* solver */
-    double gravity, contact_erp, contact_margin, warmstart, motor_kp, motor_kd, arm_motor_force;
+    double gravity, contact_erp, contact_margin, solver_margin, warmstart, motor_kp, motor_kd, arm_motor_force;
     double gear_erp, gear_max_force, global_erp;
     double finger_contact_stiffness, finger_contact_damping, object_contact_damping;
     double lin_damping, ang_damping, ik_lambda, ik_residual, ik_max_dtheta, limit_window;

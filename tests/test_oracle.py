@@ -1,0 +1,222 @@
+"""CPU oracle pinned against everything the reference holds for this path:
+reward / is_success / done golden vectors produced by the reference's own NumPy code
+(tools/gen_golden.py), URDF known-answer forward kinematics, Philox known-answer vector, plus
+self-consistency of the restated physics (ABA == independent numpy CRBA, statics, energy)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q_INIT = np.array([-0.009068751632859924, -0.08153217279952825, 0.09299669711139864, 1.067692645248743,
+                   0.0004018824370178429, 1.1524205092196147, -0.0004991403332530034, 0, 0])  # xarm_reach.py:33
+
+
+def test_philox_known_answer(oracle):
+    # Random123 kat_vectors: philox4x32-10, zero counter and key / all-ones / pi digits
+    assert oracle.philox(0, 0, 0, 0, 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox(0xffffffffffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff) == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox(0x299f31d0a4093822, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_fk_known_answers(oracle):
+    # computed from the URDF numbers, link7 = link_eef = panda_hand frame
+    pos, rot = oracle.fk(np.zeros(9))
+    np.testing.assert_allclose(pos[7], [0.206000, 0.000003, 0.120500], atol=1e-6)
+    pos, rot = oracle.fk(Q_INIT)
+    np.testing.assert_allclose(pos[7], [0.446773, 0.038455, 0.396464], atol=1e-6)
+    R = [[0.996473, 0.083862, -0.002933], [0.083838, -0.996451, -0.007464], [-0.003549, 0.007192, -0.999968]]
+    np.testing.assert_allclose(rot[7], R, atol=1e-6)
+    np.testing.assert_allclose(pos[8] + rot[8] @ [0, 0, 0.04], [0.446656, 0.038157, 0.356466], atol=1e-6)
+    # prismatic fingers slide along +-y of the hand frame from (0,0,0.0584)
+    q = Q_INIT.copy()
+    q[7], q[8] = 0.03, 0.01
+    pos, rot = oracle.fk(q)
+    np.testing.assert_allclose(pos[9], pos[8] + rot[8] @ [0, 0.03, 0.0584], atol=1e-12)
+    np.testing.assert_allclose(pos[10], pos[8] + rot[8] @ [0, -0.01, 0.0584], atol=1e-12)
+
+
+def test_reward_matches_reference_golden(oracle, golden_reward):
+    g = golden_reward
+    env = oracle.OraclePnP(1)
+    for rt in ("sparse", "dense_o2g"):
+        out = env.compute_reward(g["achieved_goal"], g["goal"], rt)
+        ref = g["reward_" + rt]
+        if rt == "sparse":
+            assert np.array_equal(out.astype(np.float32), ref.astype(np.float32))
+        else:
+            np.testing.assert_allclose(out, ref, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(out[:64], g["reward_single_" + rt], rtol=0, atol=1e-15)
+
+
+def test_success_and_done_match_reference_golden(oracle, golden_reward):
+    """is_success (:289-291) and done (:117) through the oracle's step(), by injecting states whose
+    object position is the golden achieved_goal 1/900 s of free fall earlier is not possible for all
+    rows, so the flags are checked through the same closed form the step uses."""
+    g = golden_reward
+    d = np.linalg.norm(g["achieved_goal"] - g["goal"], axis=1)
+    env = oracle.OraclePnP(1)
+    sparse = env.compute_reward(g["achieved_goal"], g["goal"], "sparse")
+    assert np.array_equal(sparse.astype(np.float32), g["is_success"])
+    for k, steps in enumerate((1, 49, 50)):
+        done = (sparse > 0) | (steps == 50)
+        assert np.array_equal(done.astype(np.uint8), g["done_steps_1_49_50"][:, k])
+    assert ((d < 0.05) == (sparse > 0)).all()
+
+
+def test_step_flags_and_counters(oracle):
+    E = 8
+    env = oracle.OraclePnP(E, seed=5)
+    env.reset()
+    st = env.get_state()
+    st[:4, 52] = 49   # next step is the 50th -> done by the time limit
+    st[4:, 31:34] = st[4:, 18:21] + [0, 0, 0.015]  # goal 1.5 cm above the object -> success stays within 5 cm
+    env.set_state(st)
+    obs, ag, dg, rew, done, succ = env.step(np.zeros((E, 4)))
+    assert done[:4].all() and done[4:].all()
+    assert succ[4:].all() and (rew[4:] == 1).all()
+    assert (env.state[:4, 52] == 50).all()
+    np.testing.assert_array_equal(ag, env.state[:, 18:21])
+    np.testing.assert_array_equal(dg, env.state[:, 31:34])
+
+
+def _numpy_mass_matrix(js, q):
+    """Independent joint-space inertia: M = sum_b (m Jv^T Jv + Jw^T I_w Jw), 11-link tree."""
+    def rpy(r, p, y):
+        cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+        return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                         [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], [-sp, cp * sr, cp * cr]])
+    L = js["links"]
+    R, o, ax, dof = {}, {}, {}, {}
+    nd = 0
+    for i, l in enumerate(L):
+        Rp, op = (np.eye(3), np.zeros(3)) if l["parent"] < 0 else (R[l["parent"]], o[l["parent"]])
+        Ro = rpy(*l["origin_rpy"])
+        a = np.array(l["axis"], float)
+        r = np.array(l["origin_xyz"], float)
+        Rj = np.eye(3)
+        if l["joint"] == "revolute":
+            th = q[nd]
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            Rj = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        elif l["joint"] == "prismatic":
+            r = r + Ro @ a * q[nd]
+        R[i] = Rp @ Ro @ Rj
+        o[i] = op + Rp @ r
+        ax[i] = R[i] @ a
+        dof[i] = nd if l["joint"] != "fixed" else -1
+        nd += l["joint"] != "fixed"
+    M = np.zeros((nd, nd))
+    for b, l in enumerate(L):
+        c = o[b] + R[b] @ np.array(l["com"])
+        i6 = l["inertia"]
+        Ic = np.array([[i6[0], i6[1], i6[2]], [i6[1], i6[3], i6[4]], [i6[2], i6[4], i6[5]]])
+        Iw = R[b] @ Ic @ R[b].T
+        Jv, Jw = np.zeros((3, nd)), np.zeros((3, nd))
+        j = b
+        while j >= 0:
+            if dof[j] >= 0:
+                if L[j]["joint"] == "revolute":
+                    Jv[:, dof[j]] = np.cross(ax[j], c - o[j])
+                    Jw[:, dof[j]] = ax[j]
+                else:
+                    Jv[:, dof[j]] = ax[j]
+            j = L[j]["parent"]
+        M += l["mass"] * Jv.T @ Jv + Jw.T @ Iw @ Jw
+    return M
+
+
+def test_aba_against_independent_mass_matrix(oracle):
+    js = oracle.load_model_json()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = np.concatenate([rng.uniform(-1.5, 1.5, 7), rng.uniform(0, 0.04, 2)])
+        M = _numpy_mass_matrix(js, q)
+        Minv = oracle.mass_matrix_inv(q)
+        np.testing.assert_allclose(Minv @ M, np.eye(9), atol=1e-9)
+        # forward dynamics with zero velocity: M qdd = tau - g(q); check through a potential-energy gradient
+        tau = rng.normal(size=9)
+        qdd = oracle.forward_dynamics(q, np.zeros(9), tau)
+        qdd0 = oracle.forward_dynamics(q, np.zeros(9), np.zeros(9))
+        np.testing.assert_allclose(M @ (qdd - qdd0), tau, atol=1e-9)
+
+
+def test_gravity_torque_is_potential_gradient(oracle):
+    js = oracle.load_model_json()
+
+    def potential(q):
+        pos, rot = oracle.fk(q)
+        return sum(l["mass"] * 9.8 * (pos[i] + rot[i] @ np.array(l["com"]))[2] for i, l in enumerate(js["links"]))
+    q = np.array([0.3, -0.4, 0.2, 0.9, -0.1, 0.8, 0.2, 0.02, 0.03])
+    M = _numpy_mass_matrix(js, q)
+    g = -M @ oracle.forward_dynamics(q, np.zeros(9), np.zeros(9))
+    num = np.array([(potential(q + 1e-6 * np.eye(9)[k]) - potential(q - 1e-6 * np.eye(9)[k])) / 2e-6 for k in range(9)])
+    np.testing.assert_allclose(g, num, atol=1e-6)
+
+
+def test_ik_reaches_target_with_downward_tool(oracle):
+    q = oracle.ik(Q_INIT, [0.4, 0.1, 0.25], max_iter=60)
+    pos, rot = oracle.fk(q)
+    np.testing.assert_allclose(pos[7], [0.4, 0.1, 0.25], atol=2e-4)
+    np.testing.assert_allclose(rot[7], np.diag([1.0, -1.0, -1.0]), atol=5e-3)
+
+
+def test_object_rests_on_table_and_arm_holds(oracle):
+    env = oracle.OraclePnP(4, seed=2)
+    env.reset()
+    for _ in range(40):
+        obs, ag, *_ = env.step(np.zeros((4, 4)))
+    st = env.state
+    far = np.abs(st[:, 19]) > 0.08   # objects that did not spawn between the fingers
+    assert far.any()
+    np.testing.assert_allclose(st[far, 20], 0.04, atol=2e-3)           # half height 0.04 (:72)
+    assert np.abs(st[far, 25:31]).max() < 5e-3                         # at rest
+    np.testing.assert_allclose(np.linalg.norm(st[:, 21:25], axis=1), 1.0, atol=1e-12)
+    assert np.abs(st[:, 9:18]).max() < 1e-2                            # arm holds its pose
+    assert (st[:, 7:9] >= -1e-4).all() and (st[:, 7:9] <= 0.04 + 1e-4).all()  # finger limits (urdf :402)
+
+
+def test_scripted_grasp_lifts_object(golden_rollout):
+    """reach - close - lift, the behaviour the reference's _run_demo (:310-349) documents"""
+    z = golden_rollout["grasp_states"][-1][:, 20]
+    assert (z > 0.15).sum() >= 2, z
+
+
+def test_obs_layout(oracle):
+    env = oracle.OraclePnP(3, seed=9)
+    obs, ag, dg = env.reset()
+    st = env.state
+    np.testing.assert_array_equal(obs[:, 6], st[:, 7])           # finger1 q      (:223)
+    np.testing.assert_array_equal(obs[:, 7], st[:, 16])          # finger1 qd     (:224)
+    np.testing.assert_array_equal(obs[:, 8:11], st[:, 18:21])    # object pos     (:233)
+    np.testing.assert_array_equal(obs[:, 11:15], st[:, 21:25])   # object quat    (:234)
+    np.testing.assert_array_equal(obs[:, 18:21], st[:, 28:31])   # object omega   (:236)
+    np.testing.assert_allclose(obs[:, 21:24], st[:, 18:21] - obs[:, 0:3], atol=1e-15)  # rel pos (:237)
+    np.testing.assert_allclose(obs[:, 15:18], st[:, 25:28] - obs[:, 3:6], atol=1e-15)  # rel vel (:235)
+    for e in range(3):
+        pos, rot = oracle.fk(st[e, :9])
+        np.testing.assert_allclose(obs[e, 0:3], pos[8] + rot[8] @ [0, 0, 0.04], atol=1e-12)  # hand COM (:225-226)
+
+
+def test_sampling_ranges_and_shard_invariance(oracle):
+    big = oracle.OraclePnP(16, seed=4)
+    lo = oracle.OraclePnP(8, seed=4, env_id_offset=0)
+    hi = oracle.OraclePnP(8, seed=4, env_id_offset=8)
+    np.testing.assert_array_equal(big.state[:8], lo.state)
+    np.testing.assert_array_equal(big.state[8:], hi.state)
+    js = oracle.load_model_json()["pick_and_place"]
+    s = oracle.OraclePnP(256, seed=1).state
+    assert (s[:, 18] >= js["obj_low"][0]).all() and (s[:, 18] < js["obj_high"][0]).all()
+    assert (s[:, 19] >= js["obj_low"][1]).all() and (s[:, 19] < js["obj_high"][1]).all()
+    assert (s[:, 20] == js["height_offset"]).all()
+    for k in range(3):
+        assert (s[:, 31 + k] >= js["goal_low"][k]).all() and (s[:, 31 + k] < js["goal_high"][k]).all()
+    g = oracle.OraclePnP(64, seed=1, goal_ground_rate=1.0).state
+    assert (g[:, 33] == js["goal_low"][2]).all()
+    g = oracle.OraclePnP(64, seed=1, goal_shape="ground").state
+    assert (g[:, 33] == js["height_offset"]).all()
+    g = oracle.OraclePnP(64, seed=1, init_grasp_rate=1.0).state
+    assert (g[:, 18] == js["start_gripper_pos"][0]).all() and (g[:, 19] == js["start_gripper_pos"][1]).all()

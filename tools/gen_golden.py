@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own NumPy code (run in the build container
+only, where /root/reference exists; the fixtures are committed, the reference is never copied).
+
+The reference modules import gym and pybullet at module level; neither is installed, so they are
+loaded with inert stub modules in sys.modules and only the pure-NumPy methods are called, unbound,
+on a SimpleNamespace `self` (SURVEY.md 8c 'What can be imported here'):
+  XarmPickAndPlace.compute_reward   xarm_pick_and_place.py:155  (sparse, dense_o2g)
+  XarmPickAndPlace._is_success      xarm_pick_and_place.py:289
+  XarmPickAndPlace._subgoal_distances :293
+The step's `done` expression (:117) is evaluated literally as written there.
+"""
+import importlib.util
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/gym_xarm/envs/xarm_pick_and_place.py"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def stub_modules():
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            m = _Any(self.__name__ + "." + name)
+            return m
+
+        def __call__(self, *a, **k):
+            return None
+
+    gym = _Any("gym")
+    gym.GoalEnv = object
+    for name in ("gym", "gym.utils", "gym.spaces", "gym.wrappers", "gym.wrappers.monitoring", "pybullet", "pybullet_data"):
+        mod = gym if name == "gym" else _Any(name)
+        sys.modules[name] = mod
+    sys.modules["gym"].error = _Any("gym.error")
+    sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+    sys.modules["gym"].utils = sys.modules["gym.utils"]
+    sys.modules["gym.utils"].seeding = _Any("gym.utils.seeding")
+    sys.modules["gym.wrappers.monitoring"].video_recorder = _Any("video_recorder")
+
+
+def main():
+    stub_modules()
+    spec = importlib.util.spec_from_file_location("ref_pnp", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cls = mod.XarmPickAndPlace
+    rng = np.random.default_rng(20240607)
+    n = 512
+    g = rng.uniform([0.35, -0.25, 0.025], [0.45, 0.25, 0.27], size=(n, 3))
+    # achieved goals: a mix of far points, near-threshold shells and exact hits
+    direction = rng.normal(size=(n, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    radius = np.concatenate([rng.uniform(0, 0.3, n // 2), 0.05 + rng.uniform(-2e-3, 2e-3, n // 4),
+                             rng.uniform(0, 0.05, n - n // 2 - n // 4)])
+    ag = g + direction * radius[:, None]
+    ag[:8] = g[:8]
+    out = {"achieved_goal": ag, "goal": g}
+    for rt in ("sparse", "dense_o2g"):
+        self = SimpleNamespace(config={"reward_type": rt, "num_obj": 1}, distance_threshold=0.05)
+        self._subgoal_distances = lambda a, b, s=self: cls._subgoal_distances(s, a, b)
+        out["reward_" + rt] = np.asarray(cls.compute_reward(self, ag, g, {}))
+        # single-row calls, as step() does (:116)
+        out["reward_single_" + rt] = np.array([cls.compute_reward(self, ag[i], g[i], {}) for i in range(64)])
+    succ, done = [], []
+    for i in range(n):
+        self = SimpleNamespace(goal=g[i].reshape(1, 3), distance_threshold=0.05, config={"num_obj": 1})
+        s = cls._is_success(self, ag[i], g[i])
+        succ.append(np.asarray(s).reshape(-1)[0])
+        for num_steps in (1, 49, 50):
+            # literal restatement of xarm_pick_and_place.py:117
+            d = (np.linalg.norm(ag[i] - g[i].reshape(1, 3).flatten(), axis=-1) < 0.05) or num_steps == 50
+            done.append(bool(d))
+    out["is_success"] = np.array(succ, dtype=np.float32)
+    out["done_steps_1_49_50"] = np.array(done, dtype=np.uint8).reshape(n, 3)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez(os.path.join(OUT, "pnp_reward_reference.npz"), **out)
+    print("wrote pnp_reward_reference.npz:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -48,8 +48,11 @@ constexpr int STATE_DIM = 54;
 constexpr int OBS_DIM = 24;
 constexpr int GOAL_DIM = 3;
 constexpr int ACT_DIM = 4;
-constexpr int LDS_FLOATS = 96; // S (42) + T (54)
+// per-env LDS columns: S (6x7 hand Jacobian) | T = Minv[:,0:7] S^T (9x6) | A_hh (6x6 sym) | table slots
+constexpr int LDS_S = 0, LDS_T = 42, LDS_AHH = 96, LDS_TBL = 117;
+constexpr int LDS_FLOATS = 117 + 8 * 4; // 149 floats = 596 B per env (160 KiB / 256 envs per CU = 640 B)
 constexpr int NTS = 4;         // object/table manifold slots (Bullet keeps <= 4 points)
+constexpr int NP = 2 * xm::NPAD; // finger pad spheres (both fingers)
 
 // state row layout (API edge, row-major [E, 54]; internal device storage is [54][E])
 enum { S_Q = 0, S_QD = 9, S_BP = 18, S_BQ = 21, S_BV = 25, S_BW = 28, S_GOAL = 31, S_LT = 34, S_LP = 42,
@@ -78,6 +81,15 @@ XARM_HD float xsin(float x) { return sinf(x); }
 XARM_HD double xsin(double x) { return sin(x); }
 XARM_HD float xcos(float x) { return cosf(x); }
 XARM_HD double xcos(double x) { return cos(x); }
+// joint angles stay within +-2pi: the hardware v_sin_f32 / v_cos_f32 (abs. error ~1e-6) are accurate
+// enough for the 5e-4 parity tolerance and ~40x cheaper than the ocml sinf/cosf with their large-
+// argument reduction (which made up a third of the kernel's instructions)
+#if defined(__HIPCC__) && !defined(XARM_HOST_BUILD)
+XARM_HD void xsincos(float x, float &s, float &c) { s = __sinf(x); c = __cosf(x); }
+#else
+XARM_HD void xsincos(float x, float &s, float &c) { s = sinf(x); c = cosf(x); }
+#endif
+XARM_HD void xsincos(double x, double &s, double &c) { s = sin(x); c = cos(x); }
 XARM_HD float xatan2(float y, float x) { return atan2f(y, x); }
 XARM_HD double xatan2(double y, double x) { return atan2(y, x); }
 XARM_HD float xabs(float x) { return fabsf(x); }
@@ -130,7 +142,8 @@ template <typename T> XARM_HD void fk_advance(Frame<T> &f, int i, T q) {
     f.o = f.o + f.c0 * (T)xm::ORG_P[i][0] + f.c1 * (T)xm::ORG_P[i][1] + f.c2 * (T)xm::ORG_P[i][2];
     const T c = (T)xm::ORG_C[i], s = (T)xm::ORG_S[i];
     V3<T> n1 = f.c1 * c + f.c2 * s, n2 = f.c2 * c - f.c1 * s;
-    const T cq = xcos(q), sq = xsin(q);
+    T cq, sq;
+    xsincos(q, sq, cq);
     V3<T> m0 = f.c0 * cq + n1 * sq, m1 = n1 * cq - f.c0 * sq;
     f.c0 = m0; f.c1 = m1; f.c2 = n2;
 }
@@ -276,8 +289,6 @@ template <typename T> struct PadPoint {
 };
 template <typename T> struct TablePoint {
     V3<T> r;
-    T K[6];
-    T invd[3];
     T lam[3];
     T vt;
     int id;
@@ -286,6 +297,7 @@ template <typename T> struct TablePoint {
 // ---------------------------------------------------------------------------------------------
 // one internal substep (dt = timeStep / numSubSteps): collide, unconstrained dynamics, rows, PGS, integrate
 template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds) {
+    const T idt = (T)1 / dt;
     // ---------------- kinematics + world-frame RNEA / CRBA
     SV<T> S[7];      // joint motion axes about the world origin
     RBI<T> Ib[9];    // per-body inertia, later suffix-summed into composite inertias
@@ -393,25 +405,28 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
     // Cholesky M = L L^T (in place), Linv, Minv = Linv^T Linv
     T Minv[45];
     {
+        T rd[9]; // reciprocals of the diagonal of L: one division per column instead of one per entry
 #pragma unroll
-        for (int r = 0; r < 9; r++)
+        for (int c = 0; c < 9; c++) {
 #pragma unroll
-            for (int c = 0; c <= r; c++) {
+            for (int r = c; r < 9; r++) {
                 T s = M[tri(r, c)];
 #pragma unroll
                 for (int k = 0; k < c; k++) s -= M[tri(r, k)] * M[tri(c, k)];
-                M[tri(r, c)] = (r == c) ? xsqrt(s) : s / M[tri(c, c)];
+                if (r == c) { M[tri(c, c)] = xsqrt(s); rd[c] = (T)1 / M[tri(c, c)]; }
+                else M[tri(r, c)] = s * rd[c];
             }
+        }
         T Li[45]; // inverse of L (lower)
 #pragma unroll
         for (int c = 0; c < 9; c++) {
-            Li[tri(c, c)] = (T)1 / M[tri(c, c)];
+            Li[tri(c, c)] = rd[c];
 #pragma unroll
             for (int r = c + 1; r < 9; r++) {
                 T s = (T)0;
 #pragma unroll
                 for (int k = c; k < r; k++) s -= M[tri(r, k)] * Li[tri(k, c)];
-                Li[tri(r, c)] = s / M[tri(r, r)];
+                Li[tri(r, c)] = s * rd[r];
             }
         }
 #pragma unroll
@@ -434,7 +449,6 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         dq[r] = st.qd[r] + dt * s;
     }
     // T = Minv[:, 0:7] S^T (9 x 6) -> LDS; A_hh = S T_a (6x6 sym) -> registers; T_f rows -> registers
-    T Ahh[21], Tf[2][6];
     {
         T Tm[9][6];
 #pragma unroll
@@ -459,19 +473,17 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                     const T sik = k < 3 ? comp(S[i].w, k) : comp(S[i].v, k - 3);
                     s += sik * Tm[i][l];
                 }
-                Ahh[tri(k, l)] = s;
+                lds[LDS_AHH + tri(k, l)] = s;
             }
 #pragma unroll
-        for (int k = 0; k < 6; k++) { Tf[0][k] = Tm[7][k]; Tf[1][k] = Tm[8][k]; }
-#pragma unroll
         for (int i = 0; i < 7; i++) {
-            lds[i * 6 + 0] = S[i].w.x; lds[i * 6 + 1] = S[i].w.y; lds[i * 6 + 2] = S[i].w.z;
-            lds[i * 6 + 3] = S[i].v.x; lds[i * 6 + 4] = S[i].v.y; lds[i * 6 + 5] = S[i].v.z;
+            lds[LDS_S + i * 6 + 0] = S[i].w.x; lds[LDS_S + i * 6 + 1] = S[i].w.y; lds[LDS_S + i * 6 + 2] = S[i].w.z;
+            lds[LDS_S + i * 6 + 3] = S[i].v.x; lds[LDS_S + i * 6 + 4] = S[i].v.y; lds[LDS_S + i * 6 + 5] = S[i].v.z;
         }
 #pragma unroll
         for (int r = 0; r < 9; r++)
 #pragma unroll
-            for (int k = 0; k < 6; k++) lds[42 + r * 6 + k] = Tm[r][k];
+            for (int k = 0; k < 6; k++) lds[LDS_T + r * 6 + k] = Tm[r][k];
         XARM_LDS_FENCE();
     }
 
@@ -508,7 +520,8 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         V3<T> gw = b0 * g.x + b1 * g.y + b2 * g.z;
         wb = wb + symmul(Iinv, gw) * dt;
         vb.z -= dt * (T)xm::GRAVITY;
-        const T dl = xpow((T)(1.0 - xm::LIN_DAMPING), dt), da = xpow((T)(1.0 - xm::ANG_DAMPING), dt);
+        // Bullet's pow(1 - damping, dt); dt is always timeStep / numSubSteps, folded by the header generator
+        const T dl = (T)xm::LIN_DAMP_FACTOR, da = (T)xm::ANG_DAMP_FACTOR;
         vb = vb * dl;
         wb = wb * da;
     }
@@ -529,7 +542,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             const T dist = p.z - (T)xm::TABLE_TOP_Z;
             const bool act = dist < (T)xm::SOLVER_MARGIN && xabs(p.x) <= (T)xm::TABLE_HALF_X &&
                              xabs(p.y) <= (T)xm::TABLE_HALF_Y && cnt < NTS;
-            const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist / dt : -dist / dt;
+            const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist * idt : -dist * idt;
             const T l0 = (T)xm::WARMSTART * st.lam_t[i];
 #pragma unroll
             for (int s = 0; s < NTS; s++) {
@@ -550,12 +563,14 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         // K = 1/m + C^T Iinv C, C = [r]x, columns c_j = r x e_j
         const V3<T> cx = mk<T>((T)0, P.r.z, -P.r.y), cy = mk<T>(-P.r.z, (T)0, P.r.x), cz = mk<T>(P.r.y, -P.r.x, (T)0);
         const V3<T> wx = symmul(Iinv, cx), wy = symmul(Iinv, cy), wz = symmul(Iinv, cz);
-        P.K[0] = imb + dot(cx, wx); P.K[1] = dot(cx, wy); P.K[2] = dot(cx, wz);
-        P.K[3] = imb + dot(cy, wy); P.K[4] = dot(cy, wz); P.K[5] = imb + dot(cz, wz);
-        // rows: n = +z, t1 = -y, t2 = +x (btPlaneSpace1 of (0,0,1))
-        P.invd[0] = act ? (T)1 / P.K[5] : (T)0;
-        P.invd[1] = act ? (T)1 / P.K[3] : (T)0;
-        P.invd[2] = act ? (T)1 / P.K[0] : (T)0;
+        const T K0 = imb + dot(cx, wx), K3 = imb + dot(cy, wy), K5 = imb + dot(cz, wz);
+        // slot columns in LDS: K_xy K_xz K_yy K_yz K_zz, then 1/diag of the rows n = +z, t1 = -y, t2 = +x
+        // (btPlaneSpace1 of (0,0,1))
+        lds[LDS_TBL + s * 8 + 0] = dot(cx, wy); lds[LDS_TBL + s * 8 + 1] = dot(cx, wz); lds[LDS_TBL + s * 8 + 2] = K3;
+        lds[LDS_TBL + s * 8 + 3] = dot(cy, wz); lds[LDS_TBL + s * 8 + 4] = K5;
+        lds[LDS_TBL + s * 8 + 5] = act ? (T)1 / K5 : (T)0;
+        lds[LDS_TBL + s * 8 + 6] = act ? (T)1 / K3 : (T)0;
+        lds[LDS_TBL + s * 8 + 7] = act ? (T)1 / K0 : (T)0;
         // warm start: impulse lam0 * n on the object at r
         const V3<T> fi = mk<T>((T)0, (T)0, P.lam[0]);
         vb = vb + fi * imb;
@@ -566,7 +581,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
     T m_vt[9], m_invd[9], m_lam[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        m_vt[i] = (T)xm::MOTOR_KP * (qt[i] - st.q[i]) / dt + (T)(1.0 - xm::MOTOR_KD) * dq[i];
+        m_vt[i] = (T)xm::MOTOR_KP * (qt[i] - st.q[i]) * idt + (T)(1.0 - xm::MOTOR_KD) * dq[i];
         m_invd[i] = (T)1 / Minv[tri(i, i)];
         m_lam[i] = (T)0;
     }
@@ -579,7 +594,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         const bool lo = g0 < (T)xm::LIMIT_WINDOW, hi = g1 < (T)xm::LIMIT_WINDOW;
         const T g = lo ? g0 : g1;
         la_sg[i] = lo ? (T)1 : (hi ? (T)-1 : (T)0);
-        la_vt[i] = g < (T)0 ? -(T)xm::GLOBAL_ERP * g / dt : -g / dt;
+        la_vt[i] = g < (T)0 ? -(T)xm::GLOBAL_ERP * g * idt : -g * idt;
         la_lam[i] = (T)0;
     }
     // finger joints: range (0.04) < window, both sides always present
@@ -587,28 +602,28 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const T g0 = st.q[7 + k] - (T)xm::LOWER[7 + k], g1 = (T)xm::UPPER[7 + k] - st.q[7 + k];
-        lf_vt[k][0] = g0 < (T)0 ? -(T)xm::GLOBAL_ERP * g0 / dt : -g0 / dt;
-        lf_vt[k][1] = g1 < (T)0 ? -(T)xm::GLOBAL_ERP * g1 / dt : -g1 / dt;
+        lf_vt[k][0] = g0 < (T)0 ? -(T)xm::GLOBAL_ERP * g0 * idt : -g0 * idt;
+        lf_vt[k][1] = g1 < (T)0 ? -(T)xm::GLOBAL_ERP * g1 * idt : -g1 * idt;
         lf_lam[k][0] = lf_lam[k][1] = (T)0;
     }
-    const T g_vt = -(T)(xm::GEAR_ERP * xm::GLOBAL_ERP) * (st.q[7] - st.q[8]) / dt;
+    const T g_vt = -(T)(xm::GEAR_ERP * xm::GLOBAL_ERP) * (st.q[7] - st.q[8]) * idt;
     const T g_hi = (T)(xm::GEAR_MAX_FORCE * xm::PNP_TIME_STEP);
     const T g_invd = (T)1 / (Minv[tri(7, 7)] - (T)2 * Minv[tri(8, 7)] + Minv[tri(8, 8)]);
     T g_lam = (T)0;
 
     // ---------------- (F) finger pad spheres against the object
-    PadPoint<T> pp[8];
+    PadPoint<T> pp[NP];
     bool pad_any = false;
     bool touch_f[2] = {false, false};
     const T pad_denom = dt * (T)xm::FINGER_CONTACT_STIFFNESS + (T)(xm::FINGER_CONTACT_DAMPING + xm::OBJECT_CONTACT_DAMPING);
-    const T pad_cfm = ((T)1 / pad_denom) / dt, pad_erp = dt * (T)xm::FINGER_CONTACT_STIFFNESS / pad_denom;
+    const T pad_cfm = ((T)1 / pad_denom) * idt, pad_erp = dt * (T)xm::FINGER_CONTACT_STIFFNESS / pad_denom;
     {
         T wtot[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-            const int fk = idx / 4, j = idx % 4;
+        for (int idx = 0; idx < NP; idx++) {
+            const int fk = idx / xm::NPAD, j = idx % xm::NPAD;
             const T sg = fk == 0 ? (T)1 : (T)-1;
             PadPoint<T> &P = pp[idx];
             const V3<T> c = fo[fk] + hc0 * (T)xm::PAD_C[j][0] + hc1 * (sg * (T)xm::PAD_C[j][1]) + hc2 * (T)xm::PAD_C[j][2];
@@ -645,7 +660,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             P.n = b0 * nl.x + b1 * nl.y + b2 * nl.z;
             P.p = cb + b0 * pl.x + b1 * pl.y + b2 * pl.z;
             P.t1 = plane_space(P.n);
-            P.vt = dist < (T)0 ? -pad_erp * dist / dt : -dist / dt;
+            P.vt = dist < (T)0 ? -pad_erp * dist * idt : -dist * idt;
             P.lam[0] = act ? (T)xm::WARMSTART * st.lam_p[idx] : (T)0;
             P.lam[1] = P.lam[2] = (T)0;
             P.invd[0] = P.invd[1] = P.invd[2] = (T)0;
@@ -664,14 +679,14 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                     T Y[6];
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
-                        T s = Tf[fk][a] * wf;
+                        T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
 #pragma unroll
-                        for (int b = 0; b < 6; b++) s += Ahh[symi(a, b)] * W[b];
+                        for (int b = 0; b < 6; b++) s += lds[LDS_AHH + symi(a, b)] * W[b];
                         Y[a] = s;
                     }
                     T yf = Minv[tri(7 + fk, 7 + fk)] * wf;
 #pragma unroll
-                    for (int b = 0; b < 6; b++) yf += Tf[fk][b] * W[b];
+                    for (int b = 0; b < 6; b++) yf += lds[LDS_T + (7 + fk) * 6 + b] * W[b];
                     const V3<T> va = mk<T>(Y[3], Y[4], Y[5]) + cross(mk<T>(Y[0], Y[1], Y[2]), P.p) + af * yf;
                     const V3<T> vbj = ej * imb - cross(r, symmul(Iinv, cross(r, ej)));
                     K[0][e] = va.x + vbj.x; K[1][e] = va.y + vbj.y; K[2][e] = va.z + vbj.z;
@@ -701,7 +716,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             for (int r = 0; r < 9; r++) {
                 T s = Minv[symi(r, 7)] * wtot[6] + Minv[symi(r, 8)] * wtot[7];
 #pragma unroll
-                for (int k = 0; k < 6; k++) s += lds[42 + r * 6 + k] * wtot[k];
+                for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
                 dq[r] += s;
             }
         }
@@ -718,22 +733,24 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         for (int s = 0; s < NTS; s++) {
             TablePoint<T> &P = tp[s];
             if (!XARM_ANY(P.id >= 0)) continue;
+            const T Kxy = lds[LDS_TBL + s * 8 + 0], Kxz = lds[LDS_TBL + s * 8 + 1], Kyy = lds[LDS_TBL + s * 8 + 2],
+                    Kyz = lds[LDS_TBL + s * 8 + 3], Kzz = lds[LDS_TBL + s * 8 + 4];
             V3<T> u = vb + cross(wb, P.r);
-            T dl = (P.vt - u.z) * P.invd[0];
+            T dl = (P.vt - u.z) * lds[LDS_TBL + s * 8 + 5];
             T nl = P.lam[0] + dl;
             nl = nl < (T)0 ? (T)0 : nl;
             dl = nl - P.lam[0];
             P.lam[0] = nl;
             V3<T> fi = mk<T>((T)0, (T)0, dl);
-            u = u + mk<T>(P.K[2], P.K[4], P.K[5]) * dl;
+            u = u + mk<T>(Kxz, Kyz, Kzz) * dl;
             const T lim = mu_t * P.lam[0];
-            dl = u.y * P.invd[1]; // t1 = -y: jv = -u.y, target 0
+            dl = u.y * lds[LDS_TBL + s * 8 + 6]; // t1 = -y: jv = -u.y, target 0
             nl = clampT(P.lam[1] + dl, -lim, lim);
             dl = nl - P.lam[1];
             P.lam[1] = nl;
             fi.y = -dl;
-            u = u - mk<T>(P.K[1], P.K[3], P.K[4]) * dl;
-            dl = -u.x * P.invd[2]; // t2 = +x
+            u = u - mk<T>(Kxy, Kyy, Kyz) * dl;
+            dl = -u.x * lds[LDS_TBL + s * 8 + 7]; // t2 = +x
             nl = clampT(P.lam[2] + dl, -lim, lim);
             dl = nl - P.lam[2];
             P.lam[2] = nl;
@@ -794,17 +811,17 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             for (int k = 0; k < 6; k++) {
                 T s = (T)0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) s += lds[i * 6 + k] * dq[i];
+                for (int i = 0; i < 7; i++) s += lds[LDS_S + i * 6 + k] * dq[i];
                 y[k] = s;
             }
             yf[0] = dq[7]; yf[1] = dq[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
-            for (int idx = 0; idx < 8; idx++) {
+            for (int idx = 0; idx < NP; idx++) {
                 PadPoint<T> &P = pp[idx];
                 if (!XARM_ANY(P.invd[0] != (T)0)) continue;
-                const int fk = idx / 4;
+                const int fk = idx / xm::NPAD;
                 const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
                 const V3<T> r = P.p - cb;
                 const V3<T> t2 = cross(P.n, P.t1);
@@ -834,16 +851,16 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                 const T wf = dot(af, fi);
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    T s = Tf[fk][a] * wf;
+                    T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
 #pragma unroll
-                    for (int b = 0; b < 6; b++) s += Ahh[symi(a, b)] * W[b];
+                    for (int b = 0; b < 6; b++) s += lds[LDS_AHH + symi(a, b)] * W[b];
                     y[a] += s;
                 }
 #pragma unroll
                 for (int k2 = 0; k2 < 2; k2++) {
                     T s = Minv[symi(7 + k2, 7 + fk)] * wf;
 #pragma unroll
-                    for (int b = 0; b < 6; b++) s += Tf[k2][b] * W[b];
+                    for (int b = 0; b < 6; b++) s += lds[LDS_T + (7 + k2) * 6 + b] * W[b];
                     yf[k2] += s;
                 }
 #pragma unroll
@@ -856,7 +873,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
             for (int r = 0; r < 9; r++) {
                 T s = Minv[symi(r, 7)] * wtot[6] + Minv[symi(r, 8)] * wtot[7];
 #pragma unroll
-                for (int k = 0; k < 6; k++) s += lds[42 + r * 6 + k] * wtot[k];
+                for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
                 dq[r] += s;
             }
         }
@@ -869,7 +886,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
 #pragma unroll
         for (int s = 0; s < NTS; s++) l = tp[s].id == i ? tp[s].lam[0] : l;
         st.lam_t[i] = l;
-        st.lam_p[i] = pp[i].lam[0];
+        st.lam_p[i] = i < NP ? pp[i < NP ? i : 0].lam[0] : (T)0;
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) { st.qd[i] = dq[i]; st.q[i] += dt * dq[i]; }
@@ -877,10 +894,11 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
     {
         // btTransformUtil::integrateTransform exponential map
         T ang = xsqrt(dot(wb, wb));
-        if (ang * dt > (T)0.7853981633974483) ang = (T)0.7853981633974483 / dt;
-        const T k = ang < (T)0.001 ? (T)0.5 * dt - dt * dt * dt * (T)0.020833333333 * ang * ang : xsin((T)0.5 * ang * dt) / ang;
+        if (ang * dt > (T)0.7853981633974483) ang = (T)0.7853981633974483 * idt;
+        T sw, cw;
+        xsincos((T)0.5 * ang * dt, sw, cw);
+        const T k = ang < (T)0.001 ? (T)0.5 * dt - dt * dt * dt * (T)0.020833333333 * ang * ang : sw / ang;
         const V3<T> ax = wb * k;
-        const T cw = xcos(ang * dt * (T)0.5);
         const T x = st.bq[0], y = st.bq[1], z = st.bq[2], w0 = st.bq[3];
         const T nx = cw * x + ax.x * w0 + ax.y * z - ax.z * y;
         const T ny = cw * y + ax.y * w0 + ax.z * x - ax.x * z;

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 MODEL_JSON = os.path.join(ROOT, "gym_xarm_amd", "model", "xarm7_pd.json")
 LIB_PATH = os.path.join(HERE, "libxarm_oracle.so")
 
-MAXL, MAXD, NPAD = 12, 9, 4
+MAXL, MAXD, NPAD = 12, 9, 2
 STATE_DIM, OBS_DIM, GOAL_DIM, ACT_DIM = 54, 24, 3, 4
 
 _d = C.c_double

@@ -730,10 +730,10 @@ static void substep(const xo_model *m, real *st, const real *q_target, real dt) 
             apply_row_impulse(r, dl, qd, vb, nd);
         }
     }
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 8; i++)
         if (row_t_n[i] >= 0) lam_t[i] = s.rows[row_t_n[i]].lam;
+    for (int i = 0; i < 2 * XO_NPAD; i++)
         if (row_p_n[i] >= 0) lam_p[i] = s.rows[row_p_n[i]].lam;
-    }
 
     /* --- integrate positions (semi-implicit Euler; quaternion by the exponential map of
      * btTransformUtil::integrateTransform) */

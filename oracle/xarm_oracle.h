@@ -32,7 +32,7 @@ extern "C" {
 
 #define XO_MAXL 12 /* links  */
 #define XO_MAXD 9  /* joint dofs */
-#define XO_NPAD 4  /* pad spheres per finger */
+#define XO_NPAD 2  /* pad spheres per finger */
 
 /* state / observation widths for PickAndPlace with one object (row-major [E, width]) */
 #define XO_STATE_DIM 54
@@ -83,7 +83,7 @@ typedef struct {
 } xo_pnp_cfg;
 
 /* state row layout (doubles): q[9] qd[9] box_pos[3] box_quat_xyzw[4] box_v[3] box_w[3] goal[3]
- * lam_table[8] lam_pad[8] touch mu_grasp num_steps episode */
+ * lam_table[8] lam_pad[8] (slots finger*XO_NPAD+pad, the rest unused) touch mu_grasp num_steps episode */
 
 int xo_state_dim(void);
 /* zero-pose arm, box at its episode-0 spawn, goal sampled; call xo_pnp_reset afterwards */

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libxarm_hip.so")
 
 XARM_OK = 0
 ENV_PICK_AND_PLACE = 0
-REWARD_TYPES = {"sparse": 0, "dense_o2g": 1}
+REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}
 
 EXPORTS = ["xarm_create", "xarm_destroy", "xarm_dims", "xarm_reset", "xarm_step", "xarm_compute_reward",

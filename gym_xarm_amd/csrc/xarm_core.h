@@ -114,7 +114,7 @@ struct EnvCfg {
     int64_t env_id_offset;
     float init_grasp_rate, goal_ground_rate;
     int goal_shape;  // 0 air, 1 ground
-    int reward_type; // 0 sparse, 1 dense_o2g
+    int reward_type; // 0 sparse, 1 dense_o2g, 2 dense (staged, uses the contact flags)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -945,6 +945,19 @@ template <typename T> XARM_HD void get_obs(const EnvState<T> &st, T (&obs)[OBS_D
 template <typename T> XARM_HD T reward_of(int reward_type, T dist) {
     return reward_type == 0 ? (dist < (T)xm::PNP_DISTANCE_THRESHOLD ? (T)1 : (T)0) : -dist;
 }
+XARM_HD float xtanh(float x) { return tanhf(x); }
+XARM_HD double xtanh(double x) { return tanh(x); }
+// staged dense reward, xarm_pick_and_place.py:166-175: reach [0,0.25] / grasped low 0.5 / lifted
+// 1 + hover bonus.  if_grasp = both fingers report contact points with the object after the step.
+template <typename T> XARM_HD T dense_reward(const EnvState<T> &st, const T (&obs)[OBS_DIM], T d_og) {
+    const T gx = obs[0] - (T)xm::PNP_EEF2GRIP[0] - st.bp[0] + (T)0.06;
+    const T gy = obs[1] - (T)xm::PNP_EEF2GRIP[1] - st.bp[1];
+    const T gz = obs[2] - (T)xm::PNP_EEF2GRIP[2] - st.bp[2];
+    const T d_ao = xsqrt(gx * gx + gy * gy + gz * gz);
+    if (!(st.touch > (T)0.5)) return (T)0.25 * ((T)1 - xtanh(d_ao));
+    if (st.bp[2] > (T)0.05) return (T)1 + (T)0.25 * ((T)1 - xtanh(d_og));
+    return (T)0.5;
+}
 
 // ---------------------------------------------------------------------------------------------
 // sampling: draws 0 init-grasp coin, 1-2 object xy, 3-5 goal xyz, 6 goal-on-ground coin
@@ -1038,7 +1051,7 @@ XARM_HD void env_step(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (
     const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
     const T dist = xsqrt(dx * dx + dy * dy + dz * dz);
     success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
-    reward = reward_of<T>(cfg.reward_type, dist);
+    reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
     done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
 }
 

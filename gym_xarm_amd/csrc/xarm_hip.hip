@@ -246,7 +246,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
     if (cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
-    if (cfg->reward_type != XARM_REWARD_SPARSE && cfg->reward_type != XARM_REWARD_DENSE_O2G)
+    if (cfg->reward_type != XARM_REWARD_SPARSE && cfg->reward_type != XARM_REWARD_DENSE_O2G && cfg->reward_type != XARM_REWARD_DENSE)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
     if (cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported goal_shape");
@@ -355,6 +355,8 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
 int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
     if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
+    if (h->cfg.reward_type == XARM_REWARD_DENSE)
+        return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense' depends on the contact state and cannot be relabelled");
     if (n == 0) return XARM_OK;
     k_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->cfg.reward_type, ag_dev, g_dev, n, out_dev);
     HIPCHK(h, hipGetLastError());

@@ -40,6 +40,8 @@ extern "C" {
 
 #define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
 #define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */
+#define XARM_REWARD_DENSE 2     /* staged reach/grasp/lift reward    :166-175; uses the simulator's contact
+                                   state, so xarm_compute_reward (relabelling) rejects it */
 
 #define XARM_GOAL_AIR 0    /* goal_space.sample(), z -> ground w.p. goal_ground_rate  :272-280 */
 #define XARM_GOAL_GROUND 1 /* shared xy, z = 0.025 (2i+1)                             :282-286 */

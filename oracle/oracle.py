@@ -47,7 +47,7 @@ class XoModel(C.Structure):
         ("gripper_low", _d), ("gripper_high", _d), ("height_offset", _d),
         ("start_gripper_pos", _d * 3), ("reset_finger_target", _d),
         ("finger_motor_force", _d), ("distance_threshold", _d),
-        ("obj_half", _d * 3), ("obj_mass", _d),
+        ("obj_half", _d * 3), ("obj_mass", _d), ("eef2grip", _d * 3),
         ("n_substeps", _i), ("reset_ticks", _i), ("max_episode_steps", _i), ("_pad1", _i),
     ]
 
@@ -58,7 +58,7 @@ class XoPnpCfg(C.Structure):
 
 
 JTYPE = {"fixed": 0, "revolute": 1, "prismatic": 2}
-REWARD_TYPES = {"sparse": 0, "dense_o2g": 1}
+REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}
 
 
@@ -99,7 +99,7 @@ def build_model(js=None):
                  "obj_mass", "n_substeps", "reset_ticks", "max_episode_steps"):
         setattr(m, name, p[name])
     for name, n in (("pos_low", 3), ("pos_high", 3), ("goal_low", 3), ("goal_high", 3), ("obj_low", 2),
-                    ("obj_high", 2), ("start_gripper_pos", 3), ("obj_half", 3)):
+                    ("obj_high", 2), ("start_gripper_pos", 3), ("obj_half", 3), ("eef2grip", 3)):
         arr = getattr(m, name)
         for k in range(n):
             arr[k] = p[name][k]
@@ -128,6 +128,8 @@ def lib():
         L.xo_pnp_reset.argtypes = [mp, cp, C.c_int64, dp, u8p, dp, dp, dp]
         L.xo_pnp_step.argtypes = [mp, cp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
         L.xo_pnp_compute_reward.argtypes = [mp, _i, C.c_int64, dp, dp, dp]
+        L.xo_pnp_dense_reward.argtypes = [mp, _i, dp, dp, dp]
+        L.xo_pnp_dense_reward.restype = _d
         L.xo_fk.argtypes = [mp, dp, dp, dp]
         L.xo_ik.argtypes = [mp, dp, dp, _i, dp]
         L.xo_mass_matrix_inv.argtypes = [mp, dp, dp]
@@ -191,6 +193,12 @@ class OraclePnP:
 
     def set_state(self, s):
         self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, STATE_DIM)
+
+
+def dense_reward(if_grasp, hand_com, ag, g, model=None):
+    m = model or build_model()
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (hand_com, ag, g)]
+    return float(lib().xo_pnp_dense_reward(m, int(if_grasp), _p(a[0]), _p(a[1]), _p(a[2])))
 
 
 def fk(q, model=None):

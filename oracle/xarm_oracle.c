@@ -882,6 +882,18 @@ int xo_pnp_compute_reward(const xo_model *m, int reward_type, int64_t n, const d
     return 0;
 }
 
+/* staged dense reward, xarm_pick_and_place.py:166-175; if_grasp = both fingers have contact points
+ * with object 0 after the step, grip_pos = hand COM (getLinkState(9)[0]) - eef2grip_offset */
+double xo_pnp_dense_reward(const xo_model *m, int if_grasp, const double *hand_com, const double *ag, const double *g) {
+    real gp[3] = {hand_com[0] - m->eef2grip[0] - ag[0] + 0.06, hand_com[1] - m->eef2grip[1] - ag[1],
+                  hand_com[2] - m->eef2grip[2] - ag[2]};
+    real d[3];
+    v3_sub(d, ag, g);
+    if (!if_grasp) return 0.25 * (1 - tanh(1.0 * v3_norm(gp)));
+    if (ag[2] > 0.05) return 1.0 + 0.25 * (1 - tanh(1.0 * v3_norm(d)));
+    return 0.5;
+}
+
 int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *state, const double *actions,
                 double *obs, double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success) {
     for (int64_t e = 0; e < E; e++) {
@@ -911,7 +923,10 @@ int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *sta
         real dist = v3_norm(d);
         int succ = dist < m->distance_threshold;
         success[e] = (uint8_t)succ;
-        xo_pnp_compute_reward(m, cfg->reward_type, 1, ag + e * 3, dg + e * 3, reward + e);
+        if (cfg->reward_type == 2)
+            reward[e] = xo_pnp_dense_reward(m, st[S_TOUCH] > 0.5, obs + e * XO_OBS_DIM, ag + e * 3, dg + e * 3);
+        else
+            xo_pnp_compute_reward(m, cfg->reward_type, 1, ag + e * 3, dg + e * 3, reward + e);
         done[e] = (uint8_t)(succ || ((int)st[S_STEPS] == m->max_episode_steps));
     }
     return 0;

@@ -69,7 +69,7 @@ typedef struct {
     double pos_low[3], pos_high[3], goal_low[3], goal_high[3], obj_low[2], obj_high[2];
     double gripper_low, gripper_high, height_offset, start_gripper_pos[3], reset_finger_target;
     double finger_motor_force, distance_threshold;
-    double obj_half[3], obj_mass;
+    double obj_half[3], obj_mass, eef2grip[3];
     int32_t n_substeps, reset_ticks, max_episode_steps, _pad1;
 } xo_model;
 
@@ -79,7 +79,7 @@ typedef struct {
     double init_grasp_rate;
     double goal_ground_rate;
     int32_t goal_shape;        /* 0 = 'air', 1 = 'ground' */
-    int32_t reward_type;       /* 0 = sparse, 1 = dense_o2g */
+    int32_t reward_type;       /* 0 = sparse, 1 = dense_o2g, 2 = dense (stateful, :166-175) */
 } xo_pnp_cfg;
 
 /* state row layout (doubles): q[9] qd[9] box_pos[3] box_quat_xyzw[4] box_v[3] box_w[3] goal[3]
@@ -98,6 +98,8 @@ int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *sta
 /* batched reward restatement: xarm_pick_and_place.py:155-177 (sparse, dense_o2g) */
 int xo_pnp_compute_reward(const xo_model *m, int reward_type, int64_t n, const double *ag,
                           const double *g, double *out);
+double xo_pnp_dense_reward(const xo_model *m, int if_grasp, const double *hand_com, const double *ag,
+                           const double *g);
 /* diagnostics used by tests */
 int xo_fk(const xo_model *m, const double *q, double *link_pos /*[n_links*3]*/,
           double *link_rot /*[n_links*9]*/);

@@ -215,3 +215,26 @@ def test_full_size_properties_65536(gx):
     assert (st[:, 7:9] > -5e-3).all() and (st[:, 7:9] < 0.045).all()      # limit rows are soft (ERP 0.2)
     assert ((full[2] == 0) | (full[2] == 1)).all()
     assert (st[:, 52] == 3).all() | (full[3] != 0).any()
+
+
+def test_dense_reward_on_grasp_rollout(gx, oracle, golden_rollout, parity):
+    """reward_type='dense' (:166-175): staged reward incl. the contact-flag branches, HIP vs oracle"""
+    g = golden_rollout
+    S, A = g["grasp_states"], g["grasp_actions"]
+    E = S.shape[1]
+    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=1, auto_reset=False,
+                  config=dict(gx.vec_env.CONFIG_DEFAULTS, reward_type="dense"))
+    ora = oracle.OraclePnP(E, seed=1, reward_type="dense")
+    seen = set()
+    for t in range(A.shape[0]):
+        env.set_state(S[t])
+        ora.set_state(S[t])
+        obs, rew, done, info = env.step(torch.tensor(A[t], dtype=torch.float32))
+        o = ora.step(A[t])
+        ok = (g["grasp_sens"][t] < 1e-3) & (_np(env.get_state())[:, 50] == ora.state[:, 50])
+        np.testing.assert_allclose(_np(rew)[ok], o[3][ok], atol=2e-4)
+        seen |= set(np.round(o[3][ok], 1))
+    assert 0.5 in seen and any(r > 1.0 for r in seen) and any(r < 0.3 for r in seen)   # all three stages occurred
+    with pytest.raises(Exception, match="relabel"):
+        env.compute_reward(torch.zeros(2, 3), torch.zeros(2, 3))
+    env.close()

@@ -89,3 +89,15 @@ def test_time_limit_and_auto_counter(hostcore):
         st, obs, ag, dg, rew, done, succ = hostcore.step(st, np.zeros((4, 4)), f32=1, seed=2)
         assert (st[:, 52] == k + 1).all()
         assert (done == ((k == 49) | (succ == 1))).all()
+
+
+def test_dense_reward_f64_matches_oracle(oracle, hostcore, golden_rollout):
+    g = golden_rollout
+    S, A = g["grasp_states"], g["grasp_actions"]
+    ora = oracle.OraclePnP(S.shape[1], seed=1, reward_type="dense")
+    for t in range(0, A.shape[0], 3):
+        ora.set_state(S[t])
+        o = ora.step(A[t])
+        st, obs, ag, dg, rew, done, succ = hostcore.step(S[t], A[t], f32=0, seed=1, rt=2)
+        ok = g["grasp_sens"][t] < 1e-2
+        np.testing.assert_allclose(rew[ok], o[3][ok], atol=1e-9)

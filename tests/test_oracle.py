@@ -220,3 +220,13 @@ def test_sampling_ranges_and_shard_invariance(oracle):
     assert (g[:, 33] == js["height_offset"]).all()
     g = oracle.OraclePnP(64, seed=1, init_grasp_rate=1.0).state
     assert (g[:, 18] == js["start_gripper_pos"][0]).all() and (g[:, 19] == js["start_gripper_pos"][1]).all()
+
+
+def test_dense_reward_matches_reference_golden(oracle, golden_reward):
+    """'dense' (:166-175) evaluated by the reference's own code on a scripted PyBullet stub"""
+    g = golden_reward
+    m = oracle.build_model()
+    out = np.array([oracle.dense_reward(g["dense_if_grasp"][i], g["dense_hand_com"][i], g["dense_achieved_goal"][i],
+                                        g["dense_goal"][i], m) for i in range(len(g["dense_reward"]))])
+    np.testing.assert_allclose(out, g["dense_reward"], rtol=0, atol=1e-15)
+    assert len(set(np.round(out, 3))) > 50 and (out == 0.5).any() and (out > 1.0).any()

@@ -80,6 +80,33 @@ def main():
             done.append(bool(d))
     out["is_success"] = np.array(succ, dtype=np.float32)
     out["done_steps_1_49_50"] = np.array(done, dtype=np.uint8).reshape(n, 3)
+    # 'dense' (:166-175) reads the simulator: give the reference a scripted `p` whose answers we choose
+    class FakeBullet:
+        def __init__(self):
+            self.grasp, self.hand = False, np.zeros(3)
+
+        def getContactPoints(self, *a):
+            return [(0,)] if self.grasp else []
+
+        def getLinkState(self, body, link):
+            return (tuple(self.hand),)
+    fake = FakeBullet()
+    mod.p = fake
+    nd = 256
+    hand = rng.uniform([0.3, -0.3, 0.15], [0.5, 0.3, 0.4], size=(nd, 3))
+    grasp = rng.random(nd) < 0.5
+    agd = hand - [0, 0, 0.067] + rng.normal(scale=0.03, size=(nd, 3))
+    agd[:, 2] = np.where(rng.random(nd) < 0.5, rng.uniform(0.0, 0.05, nd), rng.uniform(0.05, 0.3, nd))
+    gd = rng.uniform([0.35, -0.25, 0.025], [0.45, 0.25, 0.27], size=(nd, 3))
+    dense = []
+    for i in range(nd):
+        fake.grasp, fake.hand = bool(grasp[i]), hand[i]
+        self = SimpleNamespace(config={"reward_type": "dense", "num_obj": 1}, distance_threshold=0.05, xarm=0, legos=[1],
+                               finger1_index=10, finger2_index=11, gripper_base_index=9, eef2grip_offset=[0, 0, 0.088 - 0.021])
+        self._subgoal_distances = lambda a, b, s=self: cls._subgoal_distances(s, a, b)
+        dense.append(float(cls.compute_reward(self, agd[i], gd[i], {})))
+    out.update(dense_hand_com=hand, dense_if_grasp=grasp.astype(np.uint8), dense_achieved_goal=agd, dense_goal=gd,
+               dense_reward=np.array(dense))
     os.makedirs(OUT, exist_ok=True)
     np.savez(os.path.join(OUT, "pnp_reward_reference.npz"), **out)
     print("wrote pnp_reward_reference.npz:", {k: v.shape for k, v in out.items()})

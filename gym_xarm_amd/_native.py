@@ -8,11 +8,13 @@ LIB_PATH = os.path.join(HERE, "csrc", "libxarm_hip.so")
 
 XARM_OK = 0
 ENV_PICK_AND_PLACE = 0
+ENV_REACH = 1
+REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
 REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}
 
 EXPORTS = ["xarm_create", "xarm_destroy", "xarm_dims", "xarm_reset", "xarm_step", "xarm_compute_reward",
-           "xarm_get_state", "xarm_set_state", "xarm_debug_substeps", "xarm_timing_enable", "xarm_timing_read", "xarm_last_error",
+           "xarm_get_state", "xarm_set_state", "xarm_episode_steps", "xarm_debug_substeps", "xarm_timing_enable", "xarm_timing_read", "xarm_last_error",
            "xarm_version"]
 
 
@@ -55,6 +57,7 @@ def load(path=None):
     L.xarm_compute_reward.argtypes = [vp, fp, fp, C.c_int64, fp, vp]
     L.xarm_get_state.argtypes = [vp, fp, vp]
     L.xarm_set_state.argtypes = [vp, fp, vp]
+    L.xarm_episode_steps.argtypes = [vp, fp, vp]
     L.xarm_debug_substeps.argtypes = [vp, fp, C.c_int32, vp]
     L.xarm_timing_enable.argtypes = [vp, C.c_int32]
     L.xarm_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -180,13 +180,13 @@ template <typename T> XARM_HD V3<T> rot_error(const Frame<T> &f) {
     return mk<T>(pi * ax[0], pi * ax[1], pi * ax[2]);
 }
 
-template <typename T> XARM_HD void ik_solve(const T (&q_in)[9], V3<T> target, T (&q_out)[9]) {
+template <typename T, int MAXIT> XARM_HD void ik_arm(const T (&q_in)[7], V3<T> target, T (&q_out)[7]) {
     T q[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) q[i] = q_in[i];
     bool done = false;
 #pragma unroll 1
-    for (int it = 0; it < xm::PNP_N_SUBSTEPS; it++) {
+    for (int it = 0; it < MAXIT; it++) {
         V3<T> o[7], a[7];
         Frame<T> f = frame_identity<T>();
 #pragma unroll
@@ -254,6 +254,15 @@ template <typename T> XARM_HD void ik_solve(const T (&q_in)[9], V3<T> target, T 
     }
 #pragma unroll
     for (int i = 0; i < 7; i++) q_out[i] = q[i];
+}
+// PickAndPlace: maxNumIterations = n_substeps = 15 (:207); finger entries are passed through
+template <typename T> XARM_HD void ik_solve(const T (&q_in)[9], V3<T> target, T (&q_out)[9]) {
+    T qa[7], qo[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) qa[i] = q_in[i];
+    ik_arm<T, xm::PNP_N_SUBSTEPS>(qa, target, qo);
+#pragma unroll
+    for (int i = 0; i < 7; i++) q_out[i] = qo[i];
     q_out[7] = q_in[7];
     q_out[8] = q_in[8];
 }

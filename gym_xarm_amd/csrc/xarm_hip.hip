@@ -21,6 +21,7 @@
 #include <new>
 #include "../../include/xarm_hip.h"
 #include "xarm_core.h"
+#include "xarm_reach_core.h"
 
 namespace {
 
@@ -37,6 +38,8 @@ struct KParams {
     int64_t num_envs;
     xk::EnvCfg cfg;
     int auto_reset;
+    int state_dim;
+    xr::EnvCfg rcfg;
 };
 
 __device__ __forceinline__ void load_state(const KParams &P, int64_t e, xk::EnvState<float> &s) {
@@ -171,14 +174,14 @@ __global__ void k_compact_mask(const uint8_t *__restrict__ mask, int64_t n, int 
 // row-major [E, STATE_DIM] <-> structure-of-arrays [STATE_DIM][stride]
 __global__ void k_get_state(KParams P, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.num_envs * xk::STATE_DIM) return;
-    const int64_t e = i / xk::STATE_DIM, f = i % xk::STATE_DIM;
+    if (i >= P.num_envs * P.state_dim) return;
+    const int64_t e = i / P.state_dim, f = i % P.state_dim;
     out[i] = P.state[f * P.stride + e];
 }
 __global__ void k_set_state(KParams P, const float *__restrict__ in) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.num_envs * xk::STATE_DIM) return;
-    const int64_t e = i / xk::STATE_DIM, f = i % xk::STATE_DIM;
+    if (i >= P.num_envs * P.state_dim) return;
+    const int64_t e = i / P.state_dim, f = i % P.state_dim;
     P.state[f * P.stride + e] = in[i];
 }
 
@@ -188,6 +191,101 @@ __global__ void k_compute_reward(int reward_type, const float *__restrict__ ag, 
     if (i >= n) return;
     const float dx = ag[i * 3] - g[i * 3], dy = ag[i * 3 + 1] - g[i * 3 + 1], dz = ag[i * 3 + 2] - g[i * 3 + 2];
     out[i] = xk::reward_of<float>(reward_type, sqrtf(dx * dx + dy * dy + dz * dz));
+}
+
+// ------------------------------------------------------------------------------ XarmReach-v0
+__device__ __forceinline__ void reach_load(const KParams &P, int64_t e, xr::EnvState<float> &s) {
+    const float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < xr::ND; i++) { s.q[i] = S[(xr::R_Q + i) * n]; s.qd[i] = S[(xr::R_QD + i) * n]; s.qt[i] = S[(xr::R_QT + i) * n]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) s.goal[i] = S[(xr::R_GOAL + i) * n];
+    s.d_old = S[xr::R_DOLD * n]; s.steps = S[xr::R_STEPS * n]; s.episode = S[xr::R_EPISODE * n];
+}
+__device__ __forceinline__ void reach_store(const KParams &P, int64_t e, const xr::EnvState<float> &s) {
+    float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < xr::ND; i++) { S[(xr::R_Q + i) * n] = s.q[i]; S[(xr::R_QD + i) * n] = s.qd[i]; S[(xr::R_QT + i) * n] = s.qt[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) S[(xr::R_GOAL + i) * n] = s.goal[i];
+    S[xr::R_DOLD * n] = s.d_old; S[xr::R_STEPS * n] = s.steps; S[xr::R_EPISODE * n] = s.episode;
+}
+__device__ __forceinline__ void reach_write_obs(const float (&obs)[xr::OBS_DIM], const xr::EnvState<float> &s, int64_t e,
+                                                float *obs_out, float *ag_out, float *dg_out) {
+    float4 *o = reinterpret_cast<float4 *>(obs_out + e * xr::OBS_DIM);
+    o[0] = make_float4(obs[0], obs[1], obs[2], obs[3]);
+    o[1] = make_float4(obs[4], obs[5], obs[6], obs[7]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ag_out[e * 3 + k] = obs[k]; dg_out[e * 3 + k] = s.goal[k]; }
+}
+__global__ __launch_bounds__(WG) void k_reach_init(KParams P) {
+    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e >= P.num_envs) return;
+    xr::EnvState<float> s;
+    xr::env_init<float>(P.rcfg, e, s);
+    reach_store(P, e, s);
+}
+__global__ __launch_bounds__(WG) void k_reach_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                   float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                   float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                   uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                   int *__restrict__ done_list, int *__restrict__ done_count,
+                                                   int *__restrict__ stale_count) {
+    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e == 0 && stale_count) *stale_count = 0;
+    if (e >= P.num_envs) return;
+    xr::EnvState<float> s;
+    reach_load(P, e, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xr::OBS_DIM], reward;
+    bool done, success;
+    int fut;
+    xr::env_step<float>(P.rcfg, s, act, obs, reward, done, success, fut);
+    reach_store(P, e, s);
+    reach_write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = done ? 1 : 0;
+    succ_out[e] = success ? 1 : 0;
+    if (done && P.auto_reset) {
+        if (term_obs) {
+            float4 *o = reinterpret_cast<float4 *>(term_obs + e * xr::OBS_DIM);
+            o[0] = make_float4(obs[0], obs[1], obs[2], obs[3]);
+            o[1] = make_float4(obs[4], obs[5], obs[6], obs[7]);
+        }
+        const int pos = atomicAdd(done_count, 1);
+        done_list[pos] = (int)e;
+    }
+}
+__global__ __launch_bounds__(WG) void k_reach_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                    float *__restrict__ obs_out, float *__restrict__ ag_out,
+                                                    float *__restrict__ dg_out) {
+    const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (i >= n) return;
+    const int64_t e = list ? (int64_t)list[i] : i;
+    xr::EnvState<float> s;
+    reach_load(P, e, s);
+    float obs[xr::OBS_DIM];
+    xr::env_reset<float>(P.rcfg, e, s, obs);
+    reach_store(P, e, s);
+    if (obs_out) reach_write_obs(obs, s, e, obs_out, ag_out, dg_out);
+}
+__global__ void k_reach_compute_reward(int reward_type, const float *__restrict__ ag, const float *__restrict__ g, int64_t n,
+                                       float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = ag[i * 3] - g[i * 3], dy = ag[i * 3 + 1] - g[i * 3 + 1], dz = ag[i * 3 + 2] - g[i * 3 + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    out[i] = reward_type == 0 ? (d < (float)xmr::DISTANCE_THRESHOLD ? 1.f : 0.f) : -d;
+}
+// number of steps taken in the current episode (info['future_length'] = max_episode_steps - steps, :90)
+__global__ void k_episode_steps(KParams P, int steps_field, int32_t *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.num_envs) return;
+    out[e] = (int32_t)P.state[(int64_t)steps_field * P.stride + e];
 }
 
 } // namespace
@@ -243,12 +341,12 @@ const char *xarm_last_error(const xarm_handle *h) { return h ? h->err : g_err; }
 
 int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (!cfg || !out) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: null argument");
-    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
-    if (cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
+    const bool reach = cfg->env_kind == XARM_ENV_REACH;
+    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
+    if (!reach && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
-    if (cfg->reward_type != XARM_REWARD_SPARSE && cfg->reward_type != XARM_REWARD_DENSE_O2G && cfg->reward_type != XARM_REWARD_DENSE)
-        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
-    if (cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
+    if (cfg->reward_type < 0 || cfg->reward_type > 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
+    if (!reach && cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported goal_shape");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, XARM_E_NODEVICE, "%s", "xarm_create: no HIP device");
@@ -268,7 +366,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.cfg.goal_shape = cfg->goal_shape;
     h->kp.cfg.reward_type = cfg->reward_type;
     h->kp.auto_reset = cfg->auto_reset;
-    hipError_t e1 = hipMalloc(&h->kp.state, sizeof(float) * xk::STATE_DIM * stride);
+    h->kp.state_dim = reach ? xr::STATE_DIM : xk::STATE_DIM;
+    h->kp.rcfg.seed = cfg->seed;
+    h->kp.rcfg.env_id_offset = cfg->env_id_offset;
+    h->kp.rcfg.reward_type = cfg->reward_type;
+    hipError_t e1 = hipMalloc(&h->kp.state, sizeof(float) * h->kp.state_dim * stride);
     hipError_t e2 = hipMalloc(&h->done_list, sizeof(int) * stride);
     hipError_t e3 = hipMalloc(&h->done_count, sizeof(int) * 2);
     hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
@@ -277,10 +379,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         xarm_destroy(h);
         return XARM_E_HIP;
     }
-    hipMemset(h->kp.state, 0, sizeof(float) * xk::STATE_DIM * stride);
+    hipMemset(h->kp.state, 0, sizeof(float) * h->kp.state_dim * stride);
     hipMemset(h->done_count, 0, sizeof(int) * 2);
     hipMemset(h->mask_count, 0, sizeof(int));
-    k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
+    if (reach) k_reach_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
+    else k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
     hipError_t e5 = hipDeviceSynchronize();
     if (e5 != hipSuccess) {
         fail(nullptr, XARM_E_HIP, "xarm_create: k_init: %s", hipGetErrorString(e5));
@@ -306,13 +409,13 @@ int xarm_destroy(xarm_handle *h) {
 
 int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
     if (!out) return XARM_E_INVALID;
-    (void)h;
-    out->obs_dim = xk::OBS_DIM;
+    const bool reach = h && h->cfg.env_kind == XARM_ENV_REACH;
+    out->obs_dim = reach ? xr::OBS_DIM : xk::OBS_DIM;
     out->goal_dim = xk::GOAL_DIM;
     out->act_dim = xk::ACT_DIM;
-    out->state_dim = xk::STATE_DIM;
-    out->max_episode_steps = xm::PNP_MAX_EPISODE_STEPS;
-    out->n_substeps = xm::PNP_N_SUBSTEPS;
+    out->state_dim = reach ? xr::STATE_DIM : xk::STATE_DIM;
+    out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS;
+    out->n_substeps = reach ? xmr::N_SUBSTEPS : xm::PNP_N_SUBSTEPS;
     return XARM_OK;
 }
 
@@ -324,9 +427,11 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
     if (mask_dev) {
         HIPCHK(h, hipMemsetAsync(h->mask_count, 0, sizeof(int), st));
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
-        k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
     } else {
-        k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
     }
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
@@ -343,10 +448,18 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     const bool timed = h->timing && h->ev_created;
     if (timed && h->ev_n == xarm_handle::NEV) timing_flush(h);
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
-    k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                            terminal_obs_dev, h->done_list, cnt, stale);
+    const bool reach = h->cfg.env_kind == XARM_ENV_REACH;
+    if (reach)
+        k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                      terminal_obs_dev, h->done_list, cnt, stale);
+    else
+        k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                terminal_obs_dev, h->done_list, cnt, stale);
     if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
-    if (h->kp.auto_reset) k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+    if (h->kp.auto_reset) {
+        if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+    }
     h->step_index++;
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
@@ -355,6 +468,14 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
 int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
     if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
+    if (h->cfg.env_kind == XARM_ENV_REACH) {
+        if (h->cfg.reward_type == XARM_REACH_REWARD_DENSE_DIFF)
+            return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense_diff' is stateful (d_old) and cannot be relabelled");
+        if (n == 0) return XARM_OK;
+        k_reach_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->cfg.reward_type, ag_dev, g_dev, n, out_dev);
+        HIPCHK(h, hipGetLastError());
+        return XARM_OK;
+    }
     if (h->cfg.reward_type == XARM_REWARD_DENSE)
         return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense' depends on the contact state and cannot be relabelled");
     if (n == 0) return XARM_OK;
@@ -365,21 +486,30 @@ int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev,
 
 int xarm_get_state(xarm_handle *h, float *state_dev, void *stream) {
     if (!h || !state_dev) return XARM_E_INVALID;
-    const int64_t n = h->kp.num_envs * xk::STATE_DIM;
+    const int64_t n = h->kp.num_envs * h->kp.state_dim;
     k_get_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
 }
 int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
     if (!h || !state_dev) return XARM_E_INVALID;
-    const int64_t n = h->kp.num_envs * xk::STATE_DIM;
+    const int64_t n = h->kp.num_envs * h->kp.state_dim;
     k_set_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
+    HIPCHK(h, hipGetLastError());
+    return XARM_OK;
+}
+
+int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
+    if (!h || !steps_dev) return XARM_E_INVALID;
+    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (int)xk::S_STEPS;
+    k_episode_steps<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, field, steps_dev);
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
 }
 
 int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, void *stream) {
     if (!h || !qtarget_dev || n < 0) return XARM_E_INVALID;
+    if (h->cfg.env_kind != XARM_ENV_PICK_AND_PLACE) return fail(h, XARM_E_INVALID, "%s", "xarm_debug_substeps: PickAndPlace only");
     k_substeps<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, (hipStream_t)stream>>>(h->kp, qtarget_dev, n);
     HIPCHK(h, hipGetLastError());
     return XARM_OK;

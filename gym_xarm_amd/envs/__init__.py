@@ -1,1 +1,2 @@
 from .xarm_pick_and_place import XarmPickAndPlace  # noqa: F401
+from .xarm_reach import XarmReachEnv  # noqa: F401

@@ -30,20 +30,32 @@ class XarmPickAndPlaceVecEnv:
     """E independent XarmPickAndPlace environments stepped by hand-written HIP kernels."""
 
     metadata = {"render.modes": ["rgb_array"], "video.frames_per_second": 30}
+    ENV_KIND = _native.ENV_PICK_AND_PLACE
 
-    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True):
+    def _check_config(self, config):
         cfg = dict(CONFIG_DEFAULTS)
         cfg.update(config or {})
-        self.config = cfg
-        if cfg.get("GUI"):
-            raise NotImplementedError("GUI / rendering is outside the HIP hot path (SURVEY.md 2 #20)")
         if cfg["num_obj"] != 1:
             raise NotImplementedError("this build supports num_obj == 1")
         if cfg["reward_type"] not in _native.REWARD_TYPES:
-            # 'dense' needs contact state, 'dense_diff_o2g'/'incremental' raise in the reference itself
+            # 'dense_diff_o2g' / 'incremental' raise in the reference itself (:179, :302-308)
             raise NotImplementedError("reward_type %r" % (cfg["reward_type"],))
         if cfg["goal_shape"] not in _native.GOAL_SHAPES:
             raise NotImplementedError("goal_shape %r" % (cfg["goal_shape"],))
+        return cfg
+
+    def _native_config(self):
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND,
+                                  int(self.config["num_obj"]), _native.REWARD_TYPES[self.config["reward_type"]],
+                                  _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
+                                  float(self.config["goal_ground_rate"]), int(self._auto_reset),
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device())
+
+    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True):
+        cfg = self._check_config(config)
+        self.config = cfg
+        if cfg.get("GUI"):
+            raise NotImplementedError("GUI / rendering is outside the HIP hot path (SURVEY.md 2 #20)")
         if not torch.cuda.is_available():
             raise _native.XarmNativeError("gym_xarm_amd needs a HIP device (torch.cuda.is_available() is False); "
                                           "there is no CPU fallback")
@@ -82,11 +94,7 @@ class XarmPickAndPlaceVecEnv:
 
     # ------------------------------------------------------------------ native plumbing
     def _create(self):
-        c = _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, _native.ENV_PICK_AND_PLACE,
-                               int(self.config["num_obj"]), _native.REWARD_TYPES[self.config["reward_type"]],
-                               _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
-                               float(self.config["goal_ground_rate"]), int(self._auto_reset),
-                               self.device.index if self.device.index is not None else torch.cuda.current_device())
+        c = self._native_config()
         h = C.c_void_p(0)
         rc = self._L.xarm_create(C.byref(c), C.byref(h))
         _native.check(self._L, None, rc, "xarm_create")
@@ -122,7 +130,17 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, rc, "xarm_step")
         info = {"is_success": self._succ, "terminal_observation": self._term,
                 "TimeLimit.truncated": (self._done != 0) & (self._succ == 0)}
+        self._extra_info(info)
         return self._obs_dict(), self._rew, self._done, info
+
+    def _extra_info(self, info):
+        pass
+
+    def episode_steps(self):
+        """int32 [E]: steps taken in the current episode of every env"""
+        out = torch.empty(self.num_envs, device=self.device, dtype=torch.int32)
+        _native.check(self._L, self._h, self._L.xarm_episode_steps(self._h, _ptr(out), self._stream()), "xarm_episode_steps")
+        return out
 
     def step(self, actions):
         self.step_async(actions)
@@ -204,3 +222,34 @@ class XarmPickAndPlaceVecEnv:
             self.close()
         except Exception:
             pass
+
+
+REACH_CONFIG_DEFAULTS = {"reward_type": "sparse", "GUI": False}   # the two keys xarm_reach.py reads (:25,38)
+
+
+class XarmReachVecEnv(XarmPickAndPlaceVecEnv):
+    """E independent XarmReach-v0 environments (/root/reference/gym_xarm/envs/xarm_reach.py:9): contact-free
+    reach with the xArm gripper, obs 8 / goal 3 / action 4, 25 steps per episode, rewards sparse / dense /
+    dense_diff (:107-116), info['future_length'] (:90)."""
+
+    ENV_KIND = _native.ENV_REACH
+
+    def _check_config(self, config):
+        cfg = dict(REACH_CONFIG_DEFAULTS)
+        cfg.update(config or {})
+        if cfg["reward_type"] not in _native.REACH_REWARD_TYPES:
+            raise NotImplementedError("reward_type %r" % (cfg["reward_type"],))
+        return cfg
+
+    def _native_config(self):
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 0,
+                                  _native.REACH_REWARD_TYPES[self.config["reward_type"]], 0, 0.0, 0.0, int(self._auto_reset),
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device())
+
+    def _extra_info(self, info):
+        # with auto-reset, finished envs already report the fresh episode's counter
+        info["future_length"] = self._max_episode_steps - self.episode_steps()
+        info["TimeLimit.truncated"] = self._done != 0   # Reach ends only by the step count (:93)
+
+    def debug_substeps(self, q_target, n):
+        raise NotImplementedError

@@ -36,12 +36,19 @@ extern "C" {
 #define XARM_E_HIP (-2)       /* a HIP runtime call failed */
 #define XARM_E_NODEVICE (-3)  /* no HIP device available */
 
-#define XARM_ENV_PICK_AND_PLACE 0 /* XarmPickAndPlace-v1 / XarmPDPickAndPlace-v0 */
+#define XARM_ENV_PICK_AND_PLACE 0 /* XarmPickAndPlace-v1 / XarmPDPickAndPlace-v0 (xarm_pick_and_place.py) */
+#define XARM_ENV_REACH 1          /* XarmReach-v0 (xarm_reach.py): obs 8, 25 steps, 20 substeps of 1/4800 s;
+                                     xarm_config.num_obj / goal_shape / *_rate are ignored */
 
 #define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
 #define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */
 #define XARM_REWARD_DENSE 2     /* staged reach/grasp/lift reward    :166-175; uses the simulator's contact
                                    state, so xarm_compute_reward (relabelling) rejects it */
+
+/* XarmReach-v0 reward types, xarm_reach.py:107-116 */
+#define XARM_REACH_REWARD_SPARSE 0     /* (|ag-g| < 0.05) -> 1/0 */
+#define XARM_REACH_REWARD_DENSE 1      /* -|ag-g| */
+#define XARM_REACH_REWARD_DENSE_DIFF 2 /* d_old - d, stateful: xarm_compute_reward rejects it */
 
 #define XARM_GOAL_AIR 0    /* goal_space.sample(), z -> ground w.p. goal_ground_rate  :272-280 */
 #define XARM_GOAL_GROUND 1 /* shared xy, z = 0.025 (2i+1)                             :282-286 */
@@ -90,6 +97,10 @@ int xarm_compute_reward(xarm_handle *h, const float *achieved_goal_dev, const fl
  * used for parity injection and snapshots */
 int xarm_get_state(xarm_handle *h, float *state_dev, void *stream);
 int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream);
+
+/* steps taken in the current episode, int32 [E]; XarmReachEnv's info['future_length'] (xarm_reach.py:90) is
+ * max_episode_steps - steps */
+int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream);
 
 /* test hook: advance every env by n internal substeps (dt = 1/900 s) toward the joint targets
  * qtarget_dev [E,9]; no action / IK / observation logic.  Used by the substep-level parity tests. */

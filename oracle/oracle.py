@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 MODEL_JSON = os.path.join(ROOT, "gym_xarm_amd", "model", "xarm7_pd.json")
 LIB_PATH = os.path.join(HERE, "libxarm_oracle.so")
 
-MAXL, MAXD, NPAD = 12, 9, 2
+MAXL, MAXD, NPAD = 16, 13, 2
 STATE_DIM, OBS_DIM, GOAL_DIM, ACT_DIM = 54, 24, 3, 4
 
 _d = C.c_double
@@ -52,6 +52,19 @@ class XoModel(C.Structure):
     ]
 
 
+class XoReachCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("reward_type", _i), ("driver_link", _i),
+                ("time_step", _d), ("action_dt", _d), ("max_vel", _d), ("max_gripper_vel", _d),
+                ("pos_low", _d * 3), ("pos_high", _d * 3), ("goal_low", _d * 3), ("goal_high", _d * 3),
+                ("motor_force", _d), ("distance_threshold", _d), ("joint_init_pos", _d * MAXD),
+                ("n_substeps", _i), ("max_episode_steps", _i)]
+
+
+REACH_JSON = os.path.join(ROOT, "gym_xarm_amd", "model", "xarm7_reach.json")
+REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
+REACH_STATE_DIM, REACH_OBS_DIM = 45, 8
+
+
 class XoPnpCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("init_grasp_rate", _d),
                 ("goal_ground_rate", _d), ("goal_shape", _i), ("reward_type", _i)]
@@ -84,14 +97,17 @@ def build_model(js=None):
             m.inertia[i][k] = l["inertia"][k]
         m.lower[i], m.upper[i], m.damping[i], m.mass[i] = l["lower"], l["upper"], l["damping"], l["mass"]
     m.eef_link, m.hand_link = js["eef_link"], js["hand_link"]
-    m.finger_link[0], m.finger_link[1] = js["finger_links"]
-    m.pad_radius = js["pads"]["radius"]
-    for j in range(NPAD):
-        for k in range(3):
-            m.pad_center_left[j][k] = js["pads"]["centers_left"][j][k]
+    if "finger_links" in js:
+        m.finger_link[0], m.finger_link[1] = js["finger_links"]
+        m.pad_radius = js["pads"]["radius"]
+        for j in range(NPAD):
+            for k in range(3):
+                m.pad_center_left[j][k] = js["pads"]["centers_left"][j][k]
     for k, v in js["solver"].items():
         if not k.startswith("_"):
             setattr(m, k, v)
+    if "pick_and_place" not in js:
+        return m
     m.table_half_x, m.table_half_y, m.table_top_z = js["table"]["half_x"], js["table"]["half_y"], js["table"]["top_z"]
     p = js["pick_and_place"]
     for name in ("time_step", "action_dt", "max_vel", "max_gripper_vel", "gripper_low", "gripper_high",
@@ -130,6 +146,11 @@ def lib():
         L.xo_pnp_compute_reward.argtypes = [mp, _i, C.c_int64, dp, dp, dp]
         L.xo_pnp_dense_reward.argtypes = [mp, _i, dp, dp, dp]
         L.xo_pnp_dense_reward.restype = _d
+        rp = C.POINTER(XoReachCfg)
+        L.xo_reach_init.argtypes = [mp, rp, C.c_int64, dp]
+        L.xo_reach_reset.argtypes = [mp, rp, C.c_int64, dp, u8p, dp, dp, dp]
+        L.xo_reach_step.argtypes = [mp, rp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p, C.POINTER(C.c_int32)]
+        L.xo_reach_compute_reward.argtypes = [rp, _i, C.c_int64, dp, dp, dp]
         L.xo_fk.argtypes = [mp, dp, dp, dp]
         L.xo_ik.argtypes = [mp, dp, dp, _i, dp]
         L.xo_mass_matrix_inv.argtypes = [mp, dp, dp]
@@ -195,6 +216,63 @@ class OraclePnP:
         self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, STATE_DIM)
 
 
+class OracleReach:
+    """Batched CPU XarmReach-v0 (xarm_reach.py), float64."""
+
+    def __init__(self, num_envs, seed=0, env_id_offset=0, reward_type="sparse"):
+        self.L = lib()
+        js = load_model_json(REACH_JSON)
+        self.m = build_model(js)
+        r = js["reach"]
+        c = XoReachCfg()
+        c.seed, c.env_id_offset, c.reward_type, c.driver_link = seed, env_id_offset, REACH_REWARD_TYPES[reward_type], js["driver_link"]
+        for k in ("time_step", "action_dt", "max_vel", "max_gripper_vel", "motor_force", "distance_threshold",
+                  "n_substeps", "max_episode_steps"):
+            setattr(c, k, r[k])
+        for k in ("pos_low", "pos_high", "goal_low", "goal_high"):
+            for i in range(3):
+                getattr(c, k)[i] = r[k][i]
+        for i in range(MAXD):
+            c.joint_init_pos[i] = r["joint_init_pos"][i]
+        self.cfg = c
+        self.E = int(num_envs)
+        self.state = np.zeros((self.E, REACH_STATE_DIM))
+        self.L.xo_reach_init(self.m, self.cfg, self.E, _p(self.state))
+
+    def _bufs(self):
+        return np.zeros((self.E, REACH_OBS_DIM)), np.zeros((self.E, 3)), np.zeros((self.E, 3))
+
+    def reset(self, mask=None):
+        obs, ag, dg = self._bufs()
+        mk = None if mask is None else _u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xo_reach_reset(self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
+        return obs, ag, dg
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.E, ACT_DIM)
+        obs, ag, dg = self._bufs()
+        rew, done, succ = np.zeros(self.E), np.zeros(self.E, np.uint8), np.zeros(self.E, np.uint8)
+        fut = np.zeros(self.E, np.int32)
+        self.L.xo_reach_step(self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg), _p(rew),
+                             _u8(done), _u8(succ), fut.ctypes.data_as(C.POINTER(C.c_int32)))
+        return obs, ag, dg, rew, done, succ, fut
+
+    def compute_reward(self, ag, g, reward_type=None):
+        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, 3)
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(ag.shape[0])
+        rt = self.cfg.reward_type if reward_type is None else REACH_REWARD_TYPES[reward_type]
+        if self.L.xo_reach_compute_reward(self.cfg, rt, ag.shape[0], _p(ag), _p(g), _p(out)) != 0:
+            raise ValueError("reward_type is stateful")
+        return out
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, s):
+        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, REACH_STATE_DIM)
+
+
 def dense_reward(if_grasp, hand_com, ag, g, model=None):
     m = model or build_model()
     a = [np.ascontiguousarray(x, dtype=np.float64) for x in (hand_com, ag, g)]
@@ -203,36 +281,46 @@ def dense_reward(if_grasp, hand_com, ag, g, model=None):
 
 def fk(q, model=None):
     m = model or build_model()
-    q = np.ascontiguousarray(q, dtype=np.float64)
+    q = _padq(q)
     pos = np.zeros((m.n_links, 3))
     rot = np.zeros((m.n_links, 9))
     lib().xo_fk(m, _p(q), _p(pos), _p(rot))
     return pos, rot.reshape(-1, 3, 3)
 
 
+def num_dofs(m):
+    return sum(1 for i in range(m.n_links) if m.jtype[i] != 0)
+
+
+def _padq(q):
+    out = np.zeros(MAXD)
+    q = np.asarray(q, dtype=np.float64)
+    out[:q.shape[0]] = q
+    return out
+
+
 def ik(q, target, max_iter=15, model=None):
     m = model or build_model()
-    q = np.ascontiguousarray(q, dtype=np.float64)
     t = np.ascontiguousarray(target, dtype=np.float64)
     out = np.zeros(MAXD)
-    lib().xo_ik(m, _p(q), _p(t), max_iter, _p(out))
-    return out
+    lib().xo_ik(m, _p(_padq(q)), _p(t), max_iter, _p(out))
+    return out[:num_dofs(m)]
 
 
 def mass_matrix_inv(q, model=None):
     m = model or build_model()
-    q = np.ascontiguousarray(q, dtype=np.float64)
-    out = np.zeros((MAXD, MAXD))
-    lib().xo_mass_matrix_inv(m, _p(q), _p(out))
+    nd = num_dofs(m)
+    out = np.zeros((nd, nd))
+    lib().xo_mass_matrix_inv(m, _p(_padq(q)), _p(out))
     return out
 
 
 def forward_dynamics(q, qd, tau, model=None):
     m = model or build_model()
-    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau)]
+    a = [_padq(x) for x in (q, qd, tau)]
     out = np.zeros(MAXD)
     lib().xo_forward_dynamics(m, _p(a[0]), _p(a[1]), _p(a[2]), _p(out))
-    return out
+    return out[:num_dofs(m)]
 
 
 def philox(seed, c0, c1, c2, c3):

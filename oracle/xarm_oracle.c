@@ -447,6 +447,12 @@ static void ik_solve(const xo_model *m, const real *q_in, const real *target, in
     memcpy(q_out, q, t.nd * sizeof(real));
 }
 
+static int dof_of_link(const xo_model *m, int link) {
+    int nd = 0;
+    for (int i = 0; i < link; i++) nd += (m->jtype[i] != 0);
+    return nd;
+}
+
 /* ------------------------------------------------------------------ state row access */
 enum { S_Q = 0, S_QD = 9, S_BP = 18, S_BQ = 21, S_BV = 25, S_BW = 28, S_GOAL = 31, S_LT = 34, S_LP = 42,
        S_TOUCH = 50, S_MUG = 51, S_STEPS = 52, S_EPISODE = 53 };
@@ -847,7 +853,7 @@ static void reset_one(const xo_model *m, const xo_pnp_cfg *cfg, int64_t e, real 
     int64_t episode = (int64_t)st[S_EPISODE] + 1;
     for (int k = 0; k < m->reset_ticks; k++) {
         ik_solve(m, st + S_Q, m->start_gripper_pos, m->n_substeps, tgt);
-        tgt[XO_MAXD - 2] = tgt[XO_MAXD - 1] = m->reset_finger_target; /* the two finger dofs are last */
+        tgt[dof_of_link(m, m->finger_link[0])] = tgt[dof_of_link(m, m->finger_link[1])] = m->reset_finger_target;
         sim_tick(m, st, tgt);
     }
     sample_draws(cfg, e, episode, u);
@@ -961,6 +967,175 @@ int xo_mass_matrix_inv(const xo_model *m, const double *q, double *minv) {
         imp[k] = 1;
         aba_impulse_response(m, &t, imp, col);
         for (int r = 0; r < t.nd; r++) minv[r * t.nd + k] = col[r];
+    }
+    return 0;
+}
+
+/* ==================================================================================== XarmReach-v0
+ * /root/reference/gym_xarm/envs/xarm_reach.py: step :81-94, _set_action :131-142, _get_obs :144-161,
+ * reset/_reset_sim/_sample_goal :96-102,163-173, compute_reward :107-116, _is_success :175-177.
+ * Contact-free: the solver rows are the 13 POSITION_CONTROL motors (force 5*240, :140-142) and the
+ * joint limits; 20 substeps of 1/4800 s per env step (:16-17,51). */
+enum { R_Q = 0, R_QD = 13, R_QT = 26, R_GOAL = 39, R_DOLD = 42, R_STEPS = 43, R_EPISODE = 44 };
+
+static void reach_substep(const xo_model *m, const xo_reach_cfg *cfg, real *st, real dt) {
+    solver_t s;
+    s.m = m;
+    s.nrows = 0;
+    tree_setup(m, st + R_Q, &s.t);
+    int nd = s.t.nd;
+    real *q = st + R_Q, *qd = st + R_QD, *qt = st + R_QT;
+    real tau[XO_MAXD] = {0}, qdd[XO_MAXD], vb[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < m->n_links; i++)
+        if (s.t.dof[i] >= 0) tau[s.t.dof[i]] = -m->damping[i] * qd[s.t.dof[i]];
+    aba_forward_dynamics(m, &s.t, qd, tau, m->gravity, qdd);
+    for (int k = 0; k < nd; k++) qd[k] += dt * qdd[k];
+    for (int i = 0; i < m->n_links; i++) {
+        if (s.t.dof[i] < 0) continue;
+        int d = s.t.dof[i];
+        row_t *r = row_new(&s);
+        r->has_a = 1;
+        r->Ja[d] = 1;
+        r->vt = m->motor_kp * (qt[d] - q[d]) / dt + (1.0 - m->motor_kd) * qd[d];
+        r->hi = cfg->motor_force * cfg->time_step;
+        r->lo = -r->hi;
+        row_finish(&s, r);
+    }
+    for (int i = 0; i < m->n_links; i++) {
+        if (s.t.dof[i] < 0) continue;
+        int d = s.t.dof[i];
+        for (int side = 0; side < 2; side++) {
+            real gap = side == 0 ? q[d] - m->lower[i] : m->upper[i] - q[d];
+            if (gap >= m->limit_window) continue;
+            row_t *r = row_new(&s);
+            r->has_a = 1;
+            r->Ja[d] = side == 0 ? 1.0 : -1.0;
+            r->vt = gap < 0 ? -m->global_erp * gap / dt : -gap / dt;
+            r->lo = 0; r->hi = 1e30;
+            row_finish(&s, r);
+        }
+    }
+    for (int it = 0; it < m->num_iterations; it++)
+        for (int k = 0; k < s.nrows; k++) {
+            row_t *r = &s.rows[k];
+            real jv = 0;
+            for (int c = 0; c < nd; c++) jv += r->Ja[c] * qd[c];
+            real dl = (r->vt - jv) * r->inv_d, nl = r->lam + dl;
+            if (nl < r->lo) nl = r->lo;
+            if (nl > r->hi) nl = r->hi;
+            dl = nl - r->lam;
+            r->lam = nl;
+            apply_row_impulse(r, dl, qd, vb, nd);
+        }
+    for (int k = 0; k < nd; k++) q[k] += dt * qd[k];
+}
+static void reach_tick(const xo_model *m, const xo_reach_cfg *cfg, real *st) {
+    real dt = cfg->time_step / cfg->n_substeps;
+    for (int k = 0; k < cfg->n_substeps; k++) reach_substep(m, cfg, st, dt);
+}
+static void reach_obs(const xo_model *m, const xo_reach_cfg *cfg, const real *st, real *obs, real *ag, real *dg) {
+    tree_t t;
+    tree_setup(m, st + R_Q, &t);
+    int l = m->hand_link, dd = t.dof[cfg->driver_link];
+    real c[3], hp[3];
+    m3_vec(c, t.R[l], m->com[l]);
+    v3_add(hp, t.o[l], c);
+    for (int k = 0; k < 3; k++) {
+        real d[3] = {0, 0, 0}, J[XO_MAXD], s = 0;
+        d[k] = 1;
+        point_jacobian_row(m, &t, l, hp, d, J);
+        for (int j = 0; j < t.nd; j++) s += J[j] * st[R_QD + j];
+        obs[k] = hp[k];
+        obs[3 + k] = s;
+        ag[k] = hp[k];
+        dg[k] = st[R_GOAL + k];
+    }
+    obs[6] = st[R_Q + dd];
+    obs[7] = st[R_QD + dd];
+}
+static void reach_sample_goal(const xo_reach_cfg *cfg, int64_t env, int64_t episode, real *st) {
+    uint32_t o[4];
+    uint64_t gid = (uint64_t)(cfg->env_id_offset + env);
+    xo_philox(cfg->seed, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)episode, 0u, o);
+    for (int k = 0; k < 3; k++) st[R_GOAL + k] = cfg->goal_low[k] + u01(o[k]) * (cfg->goal_high[k] - cfg->goal_low[k]);
+}
+int xo_reach_init(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state) {
+    (void)m;
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_REACH_STATE_DIM;
+        memset(st, 0, XO_REACH_STATE_DIM * sizeof(real));
+        for (int k = 0; k < XO_MAXD; k++) st[R_Q + k] = st[R_QT + k] = cfg->joint_init_pos[k];
+        reach_sample_goal(cfg, e, 0, st);
+    }
+    return 0;
+}
+int xo_reach_reset(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state, const uint8_t *mask,
+                   double *obs, double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        real *st = state + e * XO_REACH_STATE_DIM;
+        int64_t episode = (int64_t)st[R_EPISODE] + 1;
+        /* _reset_sim :163-168: resetJointState(all joints) then one stepSimulation; the motors keep the
+         * targets of the last _set_action */
+        for (int k = 0; k < XO_MAXD; k++) { st[R_Q + k] = cfg->joint_init_pos[k]; st[R_QD + k] = 0; }
+        reach_tick(m, cfg, st);
+        reach_sample_goal(cfg, e, episode, st);
+        real o8[8], a3[3], g3[3], d[3];
+        reach_obs(m, cfg, st, o8, a3, g3);
+        v3_sub(d, a3, g3);
+        st[R_DOLD] = v3_norm(d); /* :100 */
+        st[R_STEPS] = 0;
+        st[R_EPISODE] = (real)episode;
+        if (obs) {
+            memcpy(obs + e * 8, o8, sizeof o8);
+            memcpy(ag + e * 3, a3, sizeof a3);
+            memcpy(dg + e * 3, g3, sizeof g3);
+        }
+    }
+    return 0;
+}
+int xo_reach_compute_reward(const xo_reach_cfg *cfg, int reward_type, int64_t n, const double *ag, const double *g,
+                            double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        real d[3];
+        v3_sub(d, ag + i * 3, g + i * 3);
+        real dist = v3_norm(d);
+        if (reward_type == 0) out[i] = dist < cfg->distance_threshold ? 1.0 : 0.0;
+        else if (reward_type == 1) out[i] = -dist;
+        else return -1; /* dense_diff is stateful (self.d_old) */
+    }
+    return 0;
+}
+int xo_reach_step(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state, const double *actions,
+                  double *obs, double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success,
+                  int32_t *future_length) {
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_REACH_STATE_DIM;
+        const real *act = actions + e * 4;
+        real a[4], tgt[XO_MAXD], new_pos[3];
+        tree_t t;
+        st[R_STEPS] += 1;
+        for (int k = 0; k < 4; k++) a[k] = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); /* :83 */
+        tree_setup(m, st + R_Q, &t);
+        for (int k = 0; k < 3; k++) {
+            real v = t.o[m->eef_link][k] + a[k] * cfg->max_vel * cfg->action_dt;
+            new_pos[k] = v < cfg->pos_low[k] ? cfg->pos_low[k] : (v > cfg->pos_high[k] ? cfg->pos_high[k] : v);
+        }
+        int dd = t.dof[cfg->driver_link];
+        real g = st[R_Q + dd] + a[3] * cfg->action_dt * cfg->max_gripper_vel; /* no clip, :137 */
+        ik_solve(m, st + R_Q, new_pos, cfg->n_substeps, tgt);
+        for (int k = 0; k < t.nd; k++) st[R_QT + k] = k < 7 ? tgt[k] : g; /* joints 10..16 all get new_gripper_pos :141-142 */
+        reach_tick(m, cfg, st);
+        reach_obs(m, cfg, st, obs + e * 8, ag + e * 3, dg + e * 3);
+        real d[3];
+        v3_sub(d, ag + e * 3, dg + e * 3);
+        real dist = v3_norm(d);
+        success[e] = (uint8_t)(dist < cfg->distance_threshold);
+        if (cfg->reward_type == 0) reward[e] = success[e] ? 1.0 : 0.0;
+        else if (cfg->reward_type == 1) reward[e] = -dist;
+        else { reward[e] = st[R_DOLD] - dist; st[R_DOLD] = dist; } /* :113-116 */
+        done[e] = (uint8_t)((int)st[R_STEPS] == cfg->max_episode_steps); /* :93 */
+        if (future_length) future_length[e] = cfg->max_episode_steps - (int)st[R_STEPS]; /* :90 */
     }
     return 0;
 }

@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-#define XO_MAXL 12 /* links  */
-#define XO_MAXD 9  /* joint dofs */
+#define XO_MAXL 16 /* links  */
+#define XO_MAXD 13 /* joint dofs */
 #define XO_NPAD 2  /* pad spheres per finger */
 
 /* state / observation widths for PickAndPlace with one object (row-major [E, width]) */
@@ -100,6 +100,28 @@ int xo_pnp_compute_reward(const xo_model *m, int reward_type, int64_t n, const d
                           const double *g, double *out);
 double xo_pnp_dense_reward(const xo_model *m, int if_grasp, const double *hand_com, const double *ag,
                            const double *g);
+/* ---- XarmReach-v0 (xarm_reach.py), model = gym_xarm_amd/model/xarm7_reach.json ---- */
+#define XO_REACH_STATE_DIM 45 /* q[13] qd[13] motor_target[13] goal[3] d_old num_steps episode */
+#define XO_REACH_OBS_DIM 8
+typedef struct {
+    uint64_t seed;
+    int64_t env_id_offset;
+    int32_t reward_type; /* 0 sparse, 1 dense, 2 dense_diff (xarm_reach.py:107-116) */
+    int32_t driver_link; /* link whose joint is gripper_driver_index 10 */
+    double time_step, action_dt, max_vel, max_gripper_vel;
+    double pos_low[3], pos_high[3], goal_low[3], goal_high[3];
+    double motor_force, distance_threshold;
+    double joint_init_pos[XO_MAXD];
+    int32_t n_substeps, max_episode_steps;
+} xo_reach_cfg;
+int xo_reach_init(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state);
+int xo_reach_reset(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state, const uint8_t *mask,
+                   double *obs, double *ag, double *dg);
+int xo_reach_step(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double *state, const double *actions,
+                  double *obs, double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success,
+                  int32_t *future_length);
+int xo_reach_compute_reward(const xo_reach_cfg *cfg, int reward_type, int64_t n, const double *ag, const double *g,
+                            double *out);
 /* diagnostics used by tests */
 int xo_fk(const xo_model *m, const double *q, double *link_pos /*[n_links*3]*/,
           double *link_rot /*[n_links*9]*/);

@@ -46,8 +46,8 @@ class HostCore:
     def __init__(self):
         d = os.path.join(ROOT, "tests", "hostbuild")
         so = os.path.join(d, "libxarm_host.so")
-        srcs = [os.path.join(d, "xarm_host.cpp"), os.path.join(ROOT, "gym_xarm_amd", "csrc", "xarm_core.h"),
-                os.path.join(ROOT, "gym_xarm_amd", "csrc", "xarm7_pd_model.h")]
+        srcs = [os.path.join(d, "xarm_host.cpp")] + [os.path.join(ROOT, "gym_xarm_amd", "csrc", f) for f in (
+            "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                                    "-o", so, srcs[0]])
@@ -92,6 +92,31 @@ class HostCore:
         st = np.array(state, dtype=np.float64, copy=True)
         self.L.xh_substep(C.c_int(f32), C.c_int64(st.shape[0]), self._p(st), self._p(np.ascontiguousarray(qt, dtype=np.float64)), C.c_int(n))
         return st
+
+    def reach_init(self, E, f32=1, seed=0, off=0, rt=0):
+        st = np.zeros((E, 45))
+        self.L.xh_reach_init(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st))
+        return st
+
+    def reach_step(self, state, actions, f32=1, seed=0, off=0, rt=0):
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 8)), np.zeros((E, 3)), np.zeros((E, 3))
+        rew, done, succ, fut = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.zeros(E, np.int32)
+        self.L.xh_reach_step(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), self._p(a),
+                             self._p(obs), self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ),
+                             fut.ctypes.data_as(C.POINTER(C.c_int32)))
+        return st, obs, ag, dg, rew, done, succ, fut
+
+    def reach_reset(self, state, mask=None, f32=1, seed=0, off=0, rt=0):
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        obs, ag, dg = np.zeros((E, 8)), np.zeros((E, 3)), np.zeros((E, 3))
+        mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xh_reach_reset(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), mk,
+                              self._p(obs), self._p(ag), self._p(dg))
+        return st, obs, ag, dg
 
     def ik(self, q, target, f32=1):
         out = np.zeros(9)

@@ -6,6 +6,7 @@
 // is spent, and to run it under -fsanitize=address,undefined.
 #define XARM_HOST_BUILD 1
 #include "../../gym_xarm_amd/csrc/xarm_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_reach_core.h"
 #include <string.h>
 
 namespace {
@@ -79,7 +80,56 @@ template <typename T> void do_ik(const double *q, const double *target, double *
 }
 }
 
+namespace {
+template <typename T> void rload(const double *r, xr::EnvState<T> &s) {
+    for (int i = 0; i < 13; i++) { s.q[i] = (T)r[xr::R_Q + i]; s.qd[i] = (T)r[xr::R_QD + i]; s.qt[i] = (T)r[xr::R_QT + i]; }
+    for (int i = 0; i < 3; i++) s.goal[i] = (T)r[xr::R_GOAL + i];
+    s.d_old = (T)r[xr::R_DOLD]; s.steps = (T)r[xr::R_STEPS]; s.episode = (T)r[xr::R_EPISODE];
+}
+template <typename T> void rstore(const xr::EnvState<T> &s, double *r) {
+    for (int i = 0; i < 13; i++) { r[xr::R_Q + i] = s.q[i]; r[xr::R_QD + i] = s.qd[i]; r[xr::R_QT + i] = s.qt[i]; }
+    for (int i = 0; i < 3; i++) r[xr::R_GOAL + i] = s.goal[i];
+    r[xr::R_DOLD] = s.d_old; r[xr::R_STEPS] = s.steps; r[xr::R_EPISODE] = s.episode;
+}
+template <typename T> void reach_step(const xr::EnvCfg &c, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
+    for (int64_t e = 0; e < E; e++) {
+        xr::EnvState<T> s; rload(state + e * xr::STATE_DIM, s);
+        T a[4], o[xr::OBS_DIM], r; bool d, su; int f;
+        for (int k = 0; k < 4; k++) a[k] = (T)act[e * 4 + k];
+        xr::env_step<T>(c, s, a, o, r, d, su, f);
+        rstore(s, state + e * xr::STATE_DIM);
+        for (int k = 0; k < 8; k++) obs[e * 8 + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = o[k]; dg[e * 3 + k] = s.goal[k]; }
+        rew[e] = r; done[e] = d; succ[e] = su; fut[e] = f;
+    }
+}
+template <typename T> void reach_reset(const xr::EnvCfg &c, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        xr::EnvState<T> s; rload(state + e * xr::STATE_DIM, s);
+        T o[xr::OBS_DIM];
+        xr::env_reset<T>(c, e, s, o);
+        rstore(s, state + e * xr::STATE_DIM);
+        for (int k = 0; k < 8; k++) obs[e * 8 + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = o[k]; dg[e * 3 + k] = s.goal[k]; }
+    }
+}
+template <typename T> void reach_init(const xr::EnvCfg &c, int64_t E, double *state) {
+    for (int64_t e = 0; e < E; e++) { xr::EnvState<T> s; xr::env_init<T>(c, e, s); rstore(s, state + e * xr::STATE_DIM); }
+}
+}
+
 extern "C" {
+static xr::EnvCfg rcfg(uint64_t seed, int64_t off, int rt) { xr::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.reward_type = rt; return c; }
+void xh_reach_init(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state) { auto c = rcfg(seed, off, rt); if (f32) reach_init<float>(c, E, state); else reach_init<double>(c, E, state); }
+void xh_reach_step(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
+    auto c = rcfg(seed, off, rt);
+    if (f32) reach_step<float>(c, E, state, act, obs, ag, dg, rew, done, succ, fut); else reach_step<double>(c, E, state, act, obs, ag, dg, rew, done, succ, fut);
+}
+void xh_reach_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = rcfg(seed, off, rt);
+    if (f32) reach_reset<float>(c, E, state, mask, obs, ag, dg); else reach_reset<double>(c, E, state, mask, obs, ag, dg);
+}
 #define CFGARGS uint64_t seed, int64_t off, double igr, double ggr, int gs, int rt
 void xh_init(int f32, CFGARGS, int64_t E, double *state) { auto c = mkcfg(seed, off, igr, ggr, gs, rt); if (f32) do_init<float>(c, E, state); else do_init<double>(c, E, state); }
 void xh_step(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {

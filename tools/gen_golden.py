@@ -112,5 +112,43 @@ def main():
     print("wrote pnp_reward_reference.npz:", {k: v.shape for k, v in out.items()})
 
 
+def reach():
+    """XarmReachEnv.compute_reward (xarm_reach.py:107-116) incl. the stateful dense_diff, _is_success (:175-177)
+    and the done / future_length expressions of step (:88-93), evaluated by the reference's own code."""
+    stub_modules()
+    spec = importlib.util.spec_from_file_location("ref_reach", "/root/reference/gym_xarm/envs/xarm_reach.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cls = mod.XarmReachEnv
+    rng = np.random.default_rng(424242)
+    n = 512
+    g = rng.uniform([0.3, -0.25, 0.3], [0.5, 0.25, 0.4], size=(n, 3))
+    direction = rng.normal(size=(n, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    radius = np.concatenate([rng.uniform(0, 0.4, n // 2), 0.05 + rng.uniform(-2e-3, 2e-3, n // 4), rng.uniform(0, 0.05, n - n // 2 - n // 4)])
+    ag = g + direction * radius[:, None]
+    out = {"achieved_goal": ag, "goal": g}
+    for rt in ("sparse", "dense"):
+        self = SimpleNamespace(reward_type=rt, distance_threshold=0.05)
+        out["reward_" + rt] = np.asarray(cls.compute_reward(self, ag, g, {}))
+    # dense_diff along a trajectory of one env: d_old is carried by the object
+    self = SimpleNamespace(reward_type="dense_diff", distance_threshold=0.05, d_old=0.3)
+    traj = g[0] + np.cumsum(rng.normal(scale=0.02, size=(64, 3)), axis=0)
+    out["diff_traj"], out["diff_goal"], out["diff_d_old0"] = traj, g[0], np.float64(0.3)
+    out["reward_dense_diff"] = np.array([cls.compute_reward(self, traj[i], g[0], {}) for i in range(64)])
+    succ = []
+    for i in range(n):
+        self = SimpleNamespace(goal=g[i], distance_threshold=0.05)
+        succ.append(cls._is_success(self, ag[i], g[i]))
+    out["is_success"] = np.array(succ, dtype=np.float32)
+    steps = np.arange(1, 27)
+    out["steps"] = steps
+    out["done"] = np.array([s == 25 for s in steps], dtype=np.uint8)          # :93
+    out["future_length"] = np.array([25 - s for s in steps], dtype=np.int32)   # :90
+    np.savez(os.path.join(OUT, "reach_reward_reference.npz"), **out)
+    print("wrote reach_reward_reference.npz")
+
+
 if __name__ == "__main__":
     main()
+    reach()

@@ -76,5 +76,37 @@ def main():
     print("wrote", path, "lifted z:", st[-1][:, 20], "max sens rand %.2e grasp %.2e" % (out["rand_sens"].max(), sens.max()))
 
 
+def reach():
+    """XarmReach-v0: random rollout over a full episode (25 steps + the step after) of 32 envs, with the
+    oracle's sensitivity of the OBSERVABLE quantities (obs 8 + arm joints) per transition."""
+    E = 32
+    ora = O.OracleReach(E, seed=3)
+    init = ora.get_state()
+    obs0 = ora.reset()[0]
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(26, E, 4))
+    acts[2] *= 2.5
+    states, obs_l, rew_l, done_l, succ_l, fut_l, sens_l = [ora.get_state()], [], [], [], [], [], []
+    for t in range(acts.shape[0]):
+        s0 = states[-1]
+        ora.set_state(s0)
+        o = ora.step(acts[t])
+        nxt = ora.get_state()
+        sens = np.zeros(E)
+        for k in range(2):
+            sp = s0.copy()
+            sp[:, :26] += np.random.default_rng(100 * t + k).uniform(-1e-6, 1e-6, size=(E, 26))
+            ora.set_state(sp)
+            op = ora.step(acts[t])
+            sens = np.maximum(sens, np.maximum(np.abs(op[0] - o[0]).max(1), np.abs(ora.get_state()[:, :7] - nxt[:, :7]).max(1)))
+        ora.set_state(nxt)
+        states.append(nxt); obs_l.append(o[0]); rew_l.append(o[3]); done_l.append(o[4]); succ_l.append(o[5]); fut_l.append(o[6]); sens_l.append(sens)
+    path = os.path.join(ROOT, "tests", "golden", "reach_oracle_rollout.npz")
+    np.savez_compressed(path, init_state=init, reset_obs=obs0, actions=acts, states=np.stack(states), obs=np.stack(obs_l),
+                        rew=np.stack(rew_l), done=np.stack(done_l), succ=np.stack(succ_l), fut=np.stack(fut_l), sens=np.stack(sens_l))
+    print("wrote", path, "max sens %.2e" % np.max(sens_l))
+
+
 if __name__ == "__main__":
     main()
+    reach()

@@ -238,3 +238,33 @@ def test_dense_reward_on_grasp_rollout(gx, oracle, golden_rollout, parity):
     with pytest.raises(Exception, match="relabel"):
         env.compute_reward(torch.zeros(2, 3), torch.zeros(2, 3))
     env.close()
+
+
+def test_auto_reset_matches_oracle_step_then_reset(gx, oracle):
+    """auto-reset path (k_step -> done list -> k_reset) against oracle.step followed by oracle.reset(mask)"""
+    E = 128
+    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=31, config=dict(gx.vec_env.CONFIG_DEFAULTS, goal_shape="ground"))
+    ora = oracle.OraclePnP(E, seed=31, goal_shape="ground")
+    env.reset()
+    for _ in range(12):                       # let the objects settle, arm at rest
+        env.step(torch.zeros(E, 4))
+    st = _np(env.get_state()).astype(np.float64)
+    st[::2, 52] = 49
+    env.set_state(st)
+    ora.set_state(st)
+    a = torch.zeros(E, 4)
+    a[:, 2] = 0.5
+    obs, rew, done, info = env.step(a)
+    o_obs, o_ag, o_dg, o_rew, o_done, o_succ = ora.step(a.numpy().astype(np.float64))
+    assert np.array_equal(_np(done), o_done) and o_done[::2].all()
+    term = _np(info["terminal_observation"])
+    calm = np.abs(st[:, 19]) > 0.09           # object away from the fingers: well-conditioned envs
+    np.testing.assert_allclose(term[o_done.astype(bool) & calm], o_obs[o_done.astype(bool) & calm], atol=2e-3)
+    ora.reset(mask=o_done)
+    dev = _np(env.get_state()).astype(np.float64)
+    ok = calm & (np.abs(ora.state[:, 19]) > 0.09)
+    np.testing.assert_allclose(dev[ok, :31], ora.state[ok, :31], atol=4e-3)
+    np.testing.assert_allclose(dev[:, 31:34], ora.state[:, 31:34], atol=1e-6)          # goals: same counter RNG
+    assert (dev[:, 33] == np.float32(0.025)).all()                                      # goal_shape='ground'
+    assert np.array_equal(dev[:, 52:54], ora.state[:, 52:54])
+    env.close()

@@ -176,6 +176,22 @@ class XarmPickAndPlaceVecEnv:
                       "xarm_debug_substeps")
         torch.cuda.current_stream(self.device).synchronize()
 
+    def save_state(self, path):
+        """Snapshot of the full simulator state (the reference never saves env state).
+        File = safetensors with one float32 tensor [E, state_dim] + metadata."""
+        from safetensors.torch import save_file
+        save_file({"state": self.get_state().cpu()}, path,
+                  metadata={"env_kind": str(self.ENV_KIND), "num_envs": str(self.num_envs), "seed": str(self._seed),
+                            "env_id_offset": str(self._env_id_offset), "state_dim": str(self.state_dim)})
+
+    def load_state(self, path):
+        from safetensors import safe_open
+        with safe_open(path, framework="pt") as f:
+            meta = f.metadata()
+            if int(meta["env_kind"]) != self.ENV_KIND or int(meta["state_dim"]) != self.state_dim or int(meta["num_envs"]) != self.num_envs:
+                raise ValueError("snapshot %s does not match this environment (%s)" % (path, meta))
+            self.set_state(f.get_tensor("state"))
+
     @property
     def goal(self):
         return self._dg

@@ -6,7 +6,7 @@ max_episode_steps)`) plus the IDs the reference's README/test.py name (README.md
 num_envs returns the single-env object with the reference's numpy call surface.
 """
 from . import _native  # noqa: F401
-from .vec_env import XarmPickAndPlaceVecEnv, XarmReachVecEnv  # noqa: F401
+from .vec_env import XarmPickAndPlaceVecEnv, XarmReachVecEnv, XarmHandoverVecEnv  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -45,3 +45,6 @@ for _id in ("XarmPickAndPlace-v1", "XarmPDPickAndPlace-v0"):
     register(_id, "gym_xarm_amd.envs:XarmPickAndPlace", 50, "gym_xarm_amd.vec_env:XarmPickAndPlaceVecEnv")
 # gym_xarm/__init__.py:6-10
 register("XarmReach-v0", "gym_xarm_amd.envs:XarmReachEnv", 25, "gym_xarm_amd.vec_env:XarmReachVecEnv")
+# gym_xarm/__init__.py:12-16 and its README / BASELINE.json alias
+for _id in ("XarmHandover-v0", "XarmPDHandover-v0"):
+    register(_id, "gym_xarm_amd.envs:XarmHandover", 100, "gym_xarm_amd.vec_env:XarmHandoverVecEnv")

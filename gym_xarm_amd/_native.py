@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libxarm_hip.so")
 XARM_OK = 0
 ENV_PICK_AND_PLACE = 0
 ENV_REACH = 1
+ENV_HANDOVER = 2
 REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
 REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}
@@ -22,7 +23,7 @@ class XarmConfig(C.Structure):
     _fields_ = [("num_envs", C.c_int64), ("env_id_offset", C.c_int64), ("seed", C.c_uint64),
                 ("env_kind", C.c_int32), ("num_obj", C.c_int32), ("reward_type", C.c_int32),
                 ("goal_shape", C.c_int32), ("init_grasp_rate", C.c_float), ("goal_ground_rate", C.c_float),
-                ("auto_reset", C.c_int32), ("device", C.c_int32)]
+                ("auto_reset", C.c_int32), ("device", C.c_int32), ("same_side_rate", C.c_float), ("reserved", C.c_int32)]
 
 
 class XarmDims(C.Structure):

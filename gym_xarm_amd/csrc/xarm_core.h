@@ -92,6 +92,8 @@ XARM_HD void xsincos(float x, float &s, float &c) { s = sinf(x); c = cosf(x); }
 XARM_HD void xsincos(double x, double &s, double &c) { s = sin(x); c = cos(x); }
 XARM_HD float xatan2(float y, float x) { return atan2f(y, x); }
 XARM_HD double xatan2(double y, double x) { return atan2(y, x); }
+XARM_HD float xasin(float x) { return asinf(x); }
+XARM_HD double xasin(double x) { return asin(x); }
 XARM_HD float xabs(float x) { return fabsf(x); }
 XARM_HD double xabs(double x) { return fabs(x); }
 XARM_HD float xpow(float x, float y) { return powf(x, y); }
@@ -180,7 +182,7 @@ template <typename T> XARM_HD V3<T> rot_error(const Frame<T> &f) {
     return mk<T>(pi * ax[0], pi * ax[1], pi * ax[2]);
 }
 
-template <typename T, int MAXIT> XARM_HD void ik_arm(const T (&q_in)[7], V3<T> target, T (&q_out)[7]) {
+template <typename T, int MAXIT> XARM_HD void ik_arm(const T (&q_in)[7], V3<T> target, T (&q_out)[7], const Frame<T> base = frame_identity<T>()) {
     T q[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) q[i] = q_in[i];
@@ -188,7 +190,7 @@ template <typename T, int MAXIT> XARM_HD void ik_arm(const T (&q_in)[7], V3<T> t
 #pragma unroll 1
     for (int it = 0; it < MAXIT; it++) {
         V3<T> o[7], a[7];
-        Frame<T> f = frame_identity<T>();
+        Frame<T> f = base;
 #pragma unroll
         for (int i = 0; i < 7; i++) { fk_advance(f, i, q[i]); o[i] = f.o; a[i] = f.c2; }
         V3<T> ep = target - f.o;
@@ -304,14 +306,41 @@ template <typename T> struct TablePoint {
 };
 
 // ---------------------------------------------------------------------------------------------
-// one internal substep (dt = timeStep / numSubSteps): collide, unconstrained dynamics, rows, PGS, integrate
-template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds) {
+// Scene traits: what differs between the single-arm PickAndPlace scene and the dual-arm Handover scene.
+struct PnpScene {
+    static constexpr int NARMS = 1;
+    static constexpr double OBJ_HX = xm::PNP_OBJ_HALF[0], OBJ_HY = xm::PNP_OBJ_HALF[1], OBJ_HZ = xm::PNP_OBJ_HALF[2];
+    static constexpr double OBJ_MASS = xm::PNP_OBJ_MASS;
+    static constexpr double TIME_STEP = xm::PNP_TIME_STEP;              // p.setTimeStep: motor / gear max impulse = force * timeStep
+    static constexpr double FINGER_MOTOR_FORCE = xm::PNP_FINGER_MOTOR_FORCE;
+    static constexpr double LIN_DAMP_FACTOR = xm::LIN_DAMP_FACTOR, ANG_DAMP_FACTOR = xm::ANG_DAMP_FACTOR;
+    template <typename T> static XARM_HD Frame<T> base_frame(int) { return frame_identity<T>(); }
+    // support surface under the point p: the table top (:66), nothing beside it
+    template <typename T> static XARM_HD bool support(V3<T> p, T &height) {
+        height = (T)xm::TABLE_TOP_Z;
+        return xabs(p.x) <= (T)xm::TABLE_HALF_X && xabs(p.y) <= (T)xm::TABLE_HALF_Y;
+    }
+};
+// lane-pair exchange used by the dual-arm scene; the single-arm scene never exchanges
+struct NoXchg {
+    template <typename T> XARM_HD T from0(T v) const { return v; }   // value held by the lane of arm 0
+    template <typename T> XARM_HD T from1(T v) const { return v; }   // ... of arm 1
+    template <typename T> XARM_HD T partner(T v) const { return v; } // ... of the other arm
+};
+
+// ---------------------------------------------------------------------------------------------
+// one internal substep (dt = timeStep / numSubSteps): collide, unconstrained dynamics, rows, PGS, integrate.
+// Dual-arm scenes run one arm per lane: `arm` selects the base frame, `xchg.from(a, v)` returns the copy of v
+// held by the lane of arm a of the same environment (object velocities are handed over between the two
+// finger/object phases of a sweep; everything else is either per-arm or computed identically by both lanes).
+template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg>
+XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
     const T idt = (T)1 / dt;
     // ---------------- kinematics + world-frame RNEA / CRBA
     SV<T> S[7];      // joint motion axes about the world origin
     RBI<T> Ib[9];    // per-body inertia, later suffix-summed into composite inertias
     SV<T> fb[9];     // per-body bias force, later suffix-summed
-    Frame<T> f = frame_identity<T>();
+    Frame<T> f = Scene::template base_frame<T>(arm);
     SV<T> vel, acc;
     vel.w = mk<T>(0, 0, 0); vel.v = mk<T>(0, 0, 0);
     acc.w = mk<T>(0, 0, 0); acc.v = mk<T>(0, 0, (T)xm::GRAVITY);
@@ -505,11 +534,11 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         b2 = mk<T>((T)2 * (x * z + y * w), (T)2 * (y * z - x * w), (T)1 - (T)2 * (x * x + y * y));
     }
     const V3<T> cb = mk<T>(st.bp[0], st.bp[1], st.bp[2]);
-    const T hx = (T)xm::PNP_OBJ_HALF[0], hy = (T)xm::PNP_OBJ_HALF[1], hz = (T)xm::PNP_OBJ_HALF[2];
-    const T mb = (T)xm::PNP_OBJ_MASS, imb = (T)(1.0 / xm::PNP_OBJ_MASS);
-    const T Ibx = (T)(xm::PNP_OBJ_MASS / 3.0 * (xm::PNP_OBJ_HALF[1] * xm::PNP_OBJ_HALF[1] + xm::PNP_OBJ_HALF[2] * xm::PNP_OBJ_HALF[2]));
-    const T Iby = (T)(xm::PNP_OBJ_MASS / 3.0 * (xm::PNP_OBJ_HALF[0] * xm::PNP_OBJ_HALF[0] + xm::PNP_OBJ_HALF[2] * xm::PNP_OBJ_HALF[2]));
-    const T Ibz = (T)(xm::PNP_OBJ_MASS / 3.0 * (xm::PNP_OBJ_HALF[0] * xm::PNP_OBJ_HALF[0] + xm::PNP_OBJ_HALF[1] * xm::PNP_OBJ_HALF[1]));
+    const T hx = (T)Scene::OBJ_HX, hy = (T)Scene::OBJ_HY, hz = (T)Scene::OBJ_HZ;
+    const T mb = (T)Scene::OBJ_MASS, imb = (T)(1.0 / Scene::OBJ_MASS);
+    const T Ibx = (T)(Scene::OBJ_MASS / 3.0 * (Scene::OBJ_HY * Scene::OBJ_HY + Scene::OBJ_HZ * Scene::OBJ_HZ));
+    const T Iby = (T)(Scene::OBJ_MASS / 3.0 * (Scene::OBJ_HX * Scene::OBJ_HX + Scene::OBJ_HZ * Scene::OBJ_HZ));
+    const T Ibz = (T)(Scene::OBJ_MASS / 3.0 * (Scene::OBJ_HX * Scene::OBJ_HX + Scene::OBJ_HY * Scene::OBJ_HY));
     T Iinv[6];
     {
         const T ix = (T)1 / Ibx, iy = (T)1 / Iby, iz = (T)1 / Ibz;
@@ -530,7 +559,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         wb = wb + symmul(Iinv, gw) * dt;
         vb.z -= dt * (T)xm::GRAVITY;
         // Bullet's pow(1 - damping, dt); dt is always timeStep / numSubSteps, folded by the header generator
-        const T dl = (T)xm::LIN_DAMP_FACTOR, da = (T)xm::ANG_DAMP_FACTOR;
+        const T dl = (T)Scene::LIN_DAMP_FACTOR, da = (T)Scene::ANG_DAMP_FACTOR;
         vb = vb * dl;
         wb = wb * da;
     }
@@ -548,9 +577,10 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         for (int i = 0; i < 8; i++) {
             V3<T> r = b0 * ((i & 1) ? hx : -hx) + b1 * ((i & 2) ? hy : -hy) + b2 * ((i & 4) ? hz : -hz);
             V3<T> p = cb + r;
-            const T dist = p.z - (T)xm::TABLE_TOP_Z;
-            const bool act = dist < (T)xm::SOLVER_MARGIN && xabs(p.x) <= (T)xm::TABLE_HALF_X &&
-                             xabs(p.y) <= (T)xm::TABLE_HALF_Y && cnt < NTS;
+            T hsup;
+            const bool sup = Scene::template support<T>(p, hsup);
+            const T dist = p.z - hsup;
+            const bool act = dist < (T)xm::SOLVER_MARGIN && sup && cnt < NTS;
             const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist * idt : -dist * idt;
             const T l0 = (T)xm::WARMSTART * st.lam_t[i];
 #pragma unroll
@@ -594,7 +624,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         m_invd[i] = (T)1 / Minv[tri(i, i)];
         m_lam[i] = (T)0;
     }
-    const T m_hi_arm = (T)(xm::ARM_MOTOR_FORCE * xm::PNP_TIME_STEP), m_hi_fin = (T)(xm::PNP_FINGER_MOTOR_FORCE * xm::PNP_TIME_STEP);
+    const T m_hi_arm = (T)(xm::ARM_MOTOR_FORCE * Scene::TIME_STEP), m_hi_fin = (T)(Scene::FINGER_MOTOR_FORCE * Scene::TIME_STEP);
     // arm joints: range > 2 * window, so at most one side is inside the window
     T la_vt[7], la_sg[7], la_lam[7];
 #pragma unroll
@@ -616,7 +646,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         lf_lam[k][0] = lf_lam[k][1] = (T)0;
     }
     const T g_vt = -(T)(xm::GEAR_ERP * xm::GLOBAL_ERP) * (st.q[7] - st.q[8]) * idt;
-    const T g_hi = (T)(xm::GEAR_MAX_FORCE * xm::PNP_TIME_STEP);
+    const T g_hi = (T)(xm::GEAR_MAX_FORCE * Scene::TIME_STEP);
     const T g_invd = (T)1 / (Minv[tri(7, 7)] - (T)2 * Minv[tri(8, 7)] + Minv[tri(8, 8)]);
     T g_lam = (T)0;
 
@@ -630,6 +660,7 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
         T wtot[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) wtot[k] = (T)0;
+        const V3<T> vb_pre = vb, wb_pre = wb;
 #pragma unroll
         for (int idx = 0; idx < NP; idx++) {
             const int fk = idx / xm::NPAD, j = idx % xm::NPAD;
@@ -729,6 +760,15 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                 dq[r] += s;
             }
         }
+        if (Scene::NARMS == 2) {
+            // the object also receives the warm-start impulses of the other arm's pads
+            const V3<T> dv = vb - vb_pre, dw = wb - wb_pre;
+            vb = vb + mk<T>(xchg.partner(dv.x), xchg.partner(dv.y), xchg.partner(dv.z));
+            wb = wb + mk<T>(xchg.partner(dw.x), xchg.partner(dw.y), xchg.partner(dw.z));
+            // both lanes must hold bit-identical object velocities from here on: take arm 0's sum
+            vb = mk<T>(xchg.from0(vb.x), xchg.from0(vb.y), xchg.from0(vb.z));
+            wb = mk<T>(xchg.from0(wb.x), xchg.from0(wb.y), xchg.from0(wb.z));
+        }
     }
     st.touch = (touch_f[0] && touch_f[1]) ? (T)1 : (T)0;
 
@@ -813,8 +853,12 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
 #pragma unroll
             for (int r = 0; r < 9; r++) dq[r] += (Minv[symi(r, 7)] - Minv[symi(r, 8)]) * dl;
         }
-        // (F) pad points, each solved as a 3x3 block in operational space
-        if (XARM_ANY(pad_any)) {
+        // (F) pad points, each solved as a 3x3 block in operational space; with two arms the pads of arm 0 are
+        // swept first, the object velocity is handed to the other lane, then the pads of arm 1
+#pragma unroll
+        for (int ph = 0; ph < Scene::NARMS; ph++) {
+        const bool mine = Scene::NARMS == 1 || arm == ph;
+        if (XARM_ANY(pad_any && mine)) {
             T y[6], yf[2], wtot[8];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -829,13 +873,14 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
 #pragma unroll
             for (int idx = 0; idx < NP; idx++) {
                 PadPoint<T> &P = pp[idx];
-                if (!XARM_ANY(P.invd[0] != (T)0)) continue;
+                if (!XARM_ANY(P.invd[0] != (T)0 && mine)) continue;
+                const T e0 = mine ? P.invd[0] : (T)0, e1 = mine ? P.invd[1] : (T)0, e2 = mine ? P.invd[2] : (T)0;
                 const int fk = idx / xm::NPAD;
                 const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
                 const V3<T> r = P.p - cb;
                 const V3<T> t2 = cross(P.n, P.t1);
                 V3<T> u = mk<T>(y[3], y[4], y[5]) + cross(mk<T>(y[0], y[1], y[2]), P.p) + af * yf[fk] - vb - cross(wb, r);
-                T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * P.invd[0];
+                T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
                 T nl = P.lam[0] + dl;
                 nl = nl < (T)0 ? (T)0 : nl;
                 dl = nl - P.lam[0];
@@ -843,13 +888,13 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                 V3<T> fi = P.n * dl;
                 u = u + P.Kn * dl;
                 const T lim = mu_p * P.lam[0];
-                dl = -dot(P.t1, u) * P.invd[1];
+                dl = -dot(P.t1, u) * e1;
                 nl = clampT(P.lam[1] + dl, -lim, lim);
                 dl = nl - P.lam[1];
                 P.lam[1] = nl;
                 fi = fi + P.t1 * dl;
                 u = u + P.Kt1 * dl;
-                dl = -dot(t2, u) * P.invd[2];
+                dl = -dot(t2, u) * e2;
                 nl = clampT(P.lam[2] + dl, -lim, lim);
                 dl = nl - P.lam[2];
                 P.lam[2] = nl;
@@ -885,6 +930,16 @@ template <typename T, typename Lds> XARM_HD void substep(EnvState<T> &st, const 
                 for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
                 dq[r] += s;
             }
+        }
+        if (Scene::NARMS == 2) {
+            if (ph == 0) {
+                vb = mk<T>(xchg.from0(vb.x), xchg.from0(vb.y), xchg.from0(vb.z));
+                wb = mk<T>(xchg.from0(wb.x), xchg.from0(wb.y), xchg.from0(wb.z));
+            } else {
+                vb = mk<T>(xchg.from1(vb.x), xchg.from1(vb.y), xchg.from1(vb.z));
+                wb = mk<T>(xchg.from1(wb.x), xchg.from1(wb.y), xchg.from1(wb.z));
+            }
+        }
         }
     }
 

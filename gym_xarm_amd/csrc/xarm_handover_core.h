@@ -1,0 +1,210 @@
+// xarm_handover_core.h - per-lane core of XarmHandover-v0 / XarmPDHandover-v0 (dual arm, one stick).
+//
+// Reference: /root/reference/gym_xarm/envs/xarm_handover.py
+//   env_step  = XarmHandover.step   :128-139 (+ _set_action :244-297, _get_obs :299-336)
+//   env_reset = XarmHandover.reset  :141-145 (+ _reset_sim :338-368, _sample_goal :370-393)
+//   reward    = compute_reward (sparse, hard-wired :40) :164-183, _is_success :395-402
+//   tick      = one p.stepSimulation() at timeStep 1/240 (no substeps), 15 per env step (:131-132)
+// num_obj = 1 and use_stand = False (the configuration BASELINE.json names).
+//
+// Mapping: TWO lanes per environment, lane = arm.  Each lane carries one xarm7_pd arm (the same
+// 9-dof chain, CRBA, Cholesky, motor / limit / gear rows and pad blocks as PickAndPlace: xk::substep with
+// HandoverScene) plus a private copy of the object state.  Rows that involve only the object (stick /
+// table / ground) are computed identically by both lanes; the finger/object blocks are swept arm 0 first,
+// then arm 1, and the object velocity is handed from one lane to its partner in between (Xchg).  This keeps
+// the per-lane register / LDS footprint of the single-arm kernel and still is the sequential Gauss-Seidel
+// sweep T, (M L G)_0, (M L G)_1, F_0, F_1 of the oracle.
+#pragma once
+#include "xarm_core.h"
+
+namespace xh {
+using xk::V3;
+using xk::mk;
+using xk::Frame;
+using xk::clampT;
+using xk::EnvState;
+
+constexpr int STATE_DIM = 76; // q[2][9] qd[2][9] finger_target[2] obj 13 goal 3 lam_table 8 lam_pad[2][4] touch[2] mug[2] steps episode
+constexpr int OBS_DIM = 29;
+constexpr int ACT_DIM = 8;
+enum { H_Q = 0, H_QD = 18, H_FT = 36, H_BP = 38, H_BQ = 41, H_BV = 45, H_BW = 48, H_GOAL = 51, H_LT = 54, H_LP = 62,
+       H_TOUCH = 70, H_MUG = 72, H_STEPS = 74, H_EPISODE = 75 };
+
+struct EnvCfg {
+    uint64_t seed;
+    int64_t env_id_offset;
+    float same_side_rate;
+    int goal_shape; // 1 = 'ground'
+};
+
+struct HandoverScene {
+    static constexpr int NARMS = 2;
+    static constexpr double OBJ_HX = xm::HO_OBJ_HALF[0], OBJ_HY = xm::HO_OBJ_HALF[1], OBJ_HZ = xm::HO_OBJ_HALF[2];
+    static constexpr double OBJ_MASS = xm::HO_OBJ_MASS;
+    static constexpr double TIME_STEP = xm::HO_TIME_STEP;
+    static constexpr double FINGER_MOTOR_FORCE = xm::HO_FINGER_MOTOR_FORCE;
+    static constexpr double LIN_DAMP_FACTOR = xm::HO_LIN_DAMP_FACTOR, ANG_DAMP_FACTOR = xm::HO_ANG_DAMP_FACTOR;
+    // arm bases at x = -+0.6, the second yawed by pi (:50-53)
+    template <typename T> static XARM_HD Frame<T> base_frame(int arm) {
+        const T c = arm == 0 ? (T)xm::HO_BASE_COS[0] : (T)xm::HO_BASE_COS[1];
+        const T s = arm == 0 ? (T)xm::HO_BASE_SIN[0] : (T)xm::HO_BASE_SIN[1];
+        Frame<T> f;
+        f.c0 = mk<T>(c, s, (T)0); f.c1 = mk<T>(-s, c, (T)0); f.c2 = mk<T>((T)0, (T)0, (T)1);
+        f.o = arm == 0 ? mk<T>((T)xm::HO_BASE_POS[0][0], (T)xm::HO_BASE_POS[0][1], (T)xm::HO_BASE_POS[0][2])
+                       : mk<T>((T)xm::HO_BASE_POS[1][0], (T)xm::HO_BASE_POS[1][1], (T)xm::HO_BASE_POS[1][2]);
+        return f;
+    }
+    // two table tops at z = 0 for table_x_min <= |x| <= table_x_max, |y| <= 0.5 (:81-83), the ground plane at
+    // z = -0.625 (:79) everywhere else
+    template <typename T> static XARM_HD bool support(V3<T> p, T &height) {
+        const bool on_table = xk::xabs(p.x) >= (T)xm::HO_TABLE_X_MIN && xk::xabs(p.x) <= (T)xm::HO_TABLE_X_MAX &&
+                              xk::xabs(p.y) <= (T)xm::HO_TABLE_HALF_Y;
+        height = on_table ? (T)xm::TABLE_TOP_Z : (T)xm::HO_GROUND_Z;
+        return true;
+    }
+};
+
+// one lane = one arm: st.q/qd/lam_p[0..3]/touch/mug are the arm's, the rest is the lane's copy of the shared state
+template <typename T> struct Lane {
+    EnvState<T> st;
+    T ft; // finger motor target of this arm (persists across reset ticks, :265-268 vs :347-353)
+};
+
+template <typename T, typename Lds, typename Xchg> XARM_HD void tick(Lane<T> &L, const T (&qt)[9], Lds lds, int arm, Xchg x) {
+    xk::substep<T, Lds, HandoverScene, Xchg>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x);
+}
+
+template <typename T> XARM_HD V3<T> eef_pos(const Lane<T> &L, int arm) {
+    Frame<T> f = HandoverScene::base_frame<T>(arm);
+#pragma unroll
+    for (int i = 0; i < 7; i++) xk::fk_advance(f, i, L.st.q[i]);
+    return f.o;
+}
+template <typename T> XARM_HD void ik(const Lane<T> &L, int arm, V3<T> target, T (&qt)[9]) {
+    T qa[7], qo[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) qa[i] = L.st.q[i];
+    xk::ik_arm<T, xm::HO_N_TICKS>(qa, target, qo, HandoverScene::base_frame<T>(arm));
+#pragma unroll
+    for (int i = 0; i < 7; i++) qt[i] = qo[i];
+    qt[7] = qt[8] = L.ft;
+}
+
+// the 8 per-arm observation entries (:304-313): grip_pos = hand COM - eef2grip, hand COM velocity, finger q, qd
+template <typename T> XARM_HD void arm_obs(const Lane<T> &L, int arm, T (&o)[8]) {
+    Frame<T> f = HandoverScene::base_frame<T>(arm);
+    V3<T> w = mk<T>(0, 0, 0), v = mk<T>(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        xk::fk_advance(f, i, L.st.q[i]);
+        w = w + f.c2 * L.st.qd[i];
+        v = v + xk::cross(f.o, f.c2) * L.st.qd[i];
+    }
+    const V3<T> hp = f.o + f.c0 * (T)xm::HAND_COM[0] + f.c1 * (T)xm::HAND_COM[1] + f.c2 * (T)xm::HAND_COM[2];
+    const V3<T> hv = v + xk::cross(w, hp);
+    o[0] = hp.x - (T)xm::HO_EEF2GRIP[0]; o[1] = hp.y - (T)xm::HO_EEF2GRIP[1]; o[2] = hp.z - (T)xm::HO_EEF2GRIP[2];
+    o[3] = hv.x; o[4] = hv.y; o[5] = hv.z;
+    o[6] = L.st.q[7]; o[7] = L.st.qd[7];
+}
+
+// draws: 0-1 object xy, 2 mirror coin, 3-5 goal xyz, 6 same-side coin
+template <typename T> XARM_HD void draws(const EnvCfg &cfg, int64_t env, int64_t episode, T (&u)[8]) {
+    const uint64_t gid = (uint64_t)(cfg.env_id_offset + env);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        uint32_t o[4];
+        xk::philox(cfg.seed, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)episode, (uint32_t)b, o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) u[b * 4 + k] = xk::u01<T>(o[k]);
+    }
+}
+template <typename T> XARM_HD void sample_object(const T (&u)[8], Lane<T> &L) {
+    const T x = (T)xm::HO_OBJ_LOW[0] + u[0] * (T)(xm::HO_OBJ_HIGH[0] - xm::HO_OBJ_LOW[0]);
+    L.st.bp[0] = u[2] < (T)0.5 ? -x : x;
+    L.st.bp[1] = (T)xm::HO_OBJ_LOW[1] + u[1] * (T)(xm::HO_OBJ_HIGH[1] - xm::HO_OBJ_LOW[1]);
+    L.st.bp[2] = (T)xm::HO_HEIGHT_OFFSET;
+    L.st.bq[0] = L.st.bq[1] = L.st.bq[2] = (T)0; L.st.bq[3] = (T)1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.st.bv[k] = (T)0; L.st.bw[k] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { L.st.lam_t[k] = (T)0; L.st.lam_p[k] = (T)0; }
+}
+template <typename T> XARM_HD void sample_goal(const EnvCfg &cfg, const T (&u)[8], Lane<T> &L) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) L.st.goal[k] = (T)xm::HO_GOAL_LOW[k] + u[3 + k] * (T)(xm::HO_GOAL_HIGH[k] - xm::HO_GOAL_LOW[k]);
+    const bool same = u[6] < (T)cfg.same_side_rate;
+    if ((L.st.bp[0] > (T)0) != same) L.st.goal[0] = -L.st.goal[0];
+    if (cfg.goal_shape == 1) L.st.goal[2] = (T)xm::HO_HEIGHT_OFFSET;
+}
+template <typename T> XARM_HD void lane_init(const EnvCfg &cfg, int64_t env, Lane<T> &L) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { L.st.q[i] = (T)xm::HO_JOINT_INIT_POS[i]; L.st.qd[i] = (T)0; }
+    L.ft = (T)xm::HO_JOINT_INIT_POS[7];
+    L.st.touch = L.st.mug = L.st.steps = L.st.episode = (T)0;
+    T u[8];
+    draws(cfg, env, 0, u);
+    sample_object(u, L);
+    sample_goal(cfg, u, L);
+}
+
+template <typename T, typename Lds, typename Xchg>
+XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds lds, Xchg x) {
+    const int64_t episode = (int64_t)L.st.episode + 1;
+    T qt[9], u[8];
+    const V3<T> home = arm == 0 ? mk<T>((T)xm::HO_EFF_INIT_POS[0][0], (T)xm::HO_EFF_INIT_POS[0][1], (T)xm::HO_EFF_INIT_POS[0][2])
+                                : mk<T>((T)xm::HO_EFF_INIT_POS[1][0], (T)xm::HO_EFF_INIT_POS[1][1], (T)xm::HO_EFF_INIT_POS[1][2]);
+#pragma unroll 1
+    for (int k = 0; k <= xm::HO_RESET_TICKS; k++) {
+        if (k < xm::HO_RESET_TICKS) ik(L, arm, home, qt);
+        else {
+            draws(cfg, env, episode, u);
+            sample_object(u, L);
+        }
+        tick<T, Lds, Xchg>(L, qt, lds, arm, x);
+    }
+    sample_goal(cfg, u, L);
+    L.st.steps = (T)0;
+    L.st.episode = (T)episode;
+}
+
+// act = this arm's 4 action entries (:249-256)
+template <typename T, typename Lds, typename Xchg>
+XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x) {
+    L.st.steps += (T)1;
+    T a[4], qt[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = clampT(act[k], (T)-1, (T)1);
+    const V3<T> cur = eef_pos(L, arm);
+    const T sc = (T)(xm::HO_MAX_VEL * xm::HO_ACTION_DT);
+    const V3<T> lo = arm == 0 ? mk<T>((T)xm::HO_POS_LOW[0][0], (T)xm::HO_POS_LOW[0][1], (T)xm::HO_POS_LOW[0][2])
+                              : mk<T>((T)xm::HO_POS_LOW[1][0], (T)xm::HO_POS_LOW[1][1], (T)xm::HO_POS_LOW[1][2]);
+    const V3<T> hi = arm == 0 ? mk<T>((T)xm::HO_POS_HIGH[0][0], (T)xm::HO_POS_HIGH[0][1], (T)xm::HO_POS_HIGH[0][2])
+                              : mk<T>((T)xm::HO_POS_HIGH[1][0], (T)xm::HO_POS_HIGH[1][1], (T)xm::HO_POS_HIGH[1][2]);
+    const V3<T> target = mk<T>(clampT(cur.x + a[0] * sc, lo.x, hi.x), clampT(cur.y + a[1] * sc, lo.y, hi.y), clampT(cur.z + a[2] * sc, lo.z, hi.z));
+    L.ft = clampT(L.st.q[7] + a[3] * (T)(xm::HO_ACTION_DT * xm::HO_MAX_GRIPPER_VEL), (T)xm::HO_GRIPPER_LOW, (T)xm::HO_GRIPPER_HIGH);
+    ik(L, arm, target, qt);
+    L.st.mug = L.st.touch; // friction toggle from the current contact points (:269-280)
+    {
+        // clamp the stick into the play field, keep only its pitch, zero its velocity (:282-297)
+        const T qx = L.st.bq[0], qy = L.st.bq[1], qz = L.st.bq[2], qw = L.st.bq[3];
+        const T sarg = (T)2 * (qw * qy - qx * qz);
+        const T hp = (T)1.57079632679489661923;
+        const T pitch = sarg <= (T)-0.99999 ? -hp : (sarg >= (T)0.99999 ? hp : xk::xasin(sarg));
+        T sp, cp;
+        xk::xsincos((T)0.5 * pitch, sp, cp);
+        L.st.bq[0] = (T)0; L.st.bq[1] = sp; L.st.bq[2] = (T)0; L.st.bq[3] = cp;
+        L.st.bp[0] = clampT(L.st.bp[0], -(T)xm::HO_OBJ_HIGH[0], (T)xm::HO_OBJ_HIGH[0]);
+        L.st.bp[1] = clampT(L.st.bp[1], -(T)xm::HO_OBJ_HIGH[1], (T)xm::HO_OBJ_HIGH[1]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { L.st.bv[k] = (T)0; L.st.bw[k] = (T)0; }
+    }
+#pragma unroll 1
+    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg>(L, qt, lds, arm, x);
+    const T dx = L.st.bp[0] - L.st.goal[0], dy = L.st.bp[1] - L.st.goal[1], dz = L.st.bp[2] - L.st.goal[2];
+    const T dist = xk::xsqrt(dx * dx + dy * dy + dz * dz);
+    success = dist < (T)xm::HO_DISTANCE_THRESHOLD;
+    reward = dist > (T)xm::HO_DISTANCE_THRESHOLD ? (T)-1 : (T)0;   // -sum(d > thr) for one object (:177-181)
+    done = success || ((int)L.st.steps == xm::HO_MAX_EPISODE_STEPS);
+}
+
+} // namespace xh

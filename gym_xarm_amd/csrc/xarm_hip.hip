@@ -22,6 +22,7 @@
 #include "../../include/xarm_hip.h"
 #include "xarm_core.h"
 #include "xarm_reach_core.h"
+#include "xarm_handover_core.h"
 
 namespace {
 
@@ -40,6 +41,7 @@ struct KParams {
     int auto_reset;
     int state_dim;
     xr::EnvCfg rcfg;
+    xh::EnvCfg hcfg;
 };
 
 __device__ __forceinline__ void load_state(const KParams &P, int64_t e, xk::EnvState<float> &s) {
@@ -281,6 +283,128 @@ __global__ void k_reach_compute_reward(int reward_type, const float *__restrict_
     const float d = sqrtf(dx * dx + dy * dy + dz * dz);
     out[i] = reward_type == 0 ? (d < (float)xmr::DISTANCE_THRESHOLD ? 1.f : 0.f) : -d;
 }
+// --------------------------------------------------------------------- XarmHandover-v0 (two lanes per env)
+// lane-pair exchange by DPP quad permutes: lanes (2k, 2k+1) are arm 0 / arm 1 of one environment
+struct DppXchg {
+    __device__ __forceinline__ float from0(float v) const { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xA0, 0xF, 0xF, true)); }   // quad_perm [0,0,2,2]
+    __device__ __forceinline__ float from1(float v) const { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5, 0xF, 0xF, true)); }   // quad_perm [1,1,3,3]
+    __device__ __forceinline__ float partner(float v) const { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); } // quad_perm [1,0,3,2]
+};
+__device__ __forceinline__ void ho_load(const KParams &P, int64_t e, int arm, xh::Lane<float> &L) {
+    const float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { L.st.q[i] = S[(xh::H_Q + 9 * arm + i) * n]; L.st.qd[i] = S[(xh::H_QD + 9 * arm + i) * n]; }
+    L.ft = S[(xh::H_FT + arm) * n];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        L.st.bp[i] = S[(xh::H_BP + i) * n]; L.st.bv[i] = S[(xh::H_BV + i) * n];
+        L.st.bw[i] = S[(xh::H_BW + i) * n]; L.st.goal[i] = S[(xh::H_GOAL + i) * n];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { L.st.bq[i] = S[(xh::H_BQ + i) * n]; L.st.lam_p[i] = S[(xh::H_LP + 4 * arm + i) * n]; L.st.lam_p[4 + i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) L.st.lam_t[i] = S[(xh::H_LT + i) * n];
+    L.st.touch = S[(xh::H_TOUCH + arm) * n]; L.st.mug = S[(xh::H_MUG + arm) * n];
+    L.st.steps = S[xh::H_STEPS * n]; L.st.episode = S[xh::H_EPISODE * n];
+}
+__device__ __forceinline__ void ho_store(const KParams &P, int64_t e, int arm, const xh::Lane<float> &L) {
+    float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { S[(xh::H_Q + 9 * arm + i) * n] = L.st.q[i]; S[(xh::H_QD + 9 * arm + i) * n] = L.st.qd[i]; }
+    S[(xh::H_FT + arm) * n] = L.ft;
+#pragma unroll
+    for (int i = 0; i < 4; i++) S[(xh::H_LP + 4 * arm + i) * n] = L.st.lam_p[i];
+    S[(xh::H_TOUCH + arm) * n] = L.st.touch; S[(xh::H_MUG + arm) * n] = L.st.mug;
+    if (arm == 0) { // shared fields are bit-identical in both lanes
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            S[(xh::H_BP + i) * n] = L.st.bp[i]; S[(xh::H_BV + i) * n] = L.st.bv[i];
+            S[(xh::H_BW + i) * n] = L.st.bw[i]; S[(xh::H_GOAL + i) * n] = L.st.goal[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[(xh::H_BQ + i) * n] = L.st.bq[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[(xh::H_LT + i) * n] = L.st.lam_t[i];
+        S[xh::H_STEPS * n] = L.st.steps; S[xh::H_EPISODE * n] = L.st.episode;
+    }
+}
+__device__ __forceinline__ void ho_write_obs(const xh::Lane<float> &L, int64_t e, int arm, float *obs_out, float *ag_out, float *dg_out) {
+    float o8[8];
+    xh::arm_obs(L, arm, o8);
+    float *o = obs_out + e * xh::OBS_DIM;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[13 + 8 * arm + k] = o8[k];
+    if (arm == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[k] = L.st.bp[k]; o[7 + k] = L.st.bv[k]; o[10 + k] = L.st.bw[k]; ag_out[e * 3 + k] = L.st.bp[k]; dg_out[e * 3 + k] = L.st.goal[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[3 + k] = L.st.bq[k];
+    }
+}
+__global__ __launch_bounds__(WG) void k_ho_init(KParams P) {
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e = t >> 1;
+    const int arm = (int)(t & 1);
+    if (e >= P.num_envs) return;
+    xh::Lane<float> L;
+    xh::lane_init<float>(P.hcfg, e, L);
+    ho_store(P, e, arm, L);
+}
+__global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                int *__restrict__ done_list, int *__restrict__ done_count,
+                                                int *__restrict__ stale_count) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e = t >> 1;
+    const int arm = (int)(t & 1);
+    if (t == 0 && stale_count) *stale_count = 0;
+    if (e >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xh::Lane<float> L;
+    ho_load(P, e, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e * 2 + arm];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float reward;
+    bool done, success;
+    xh::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg());
+    ho_store(P, e, arm, L);
+    ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+    if (done && P.auto_reset && term_obs) ho_write_obs(L, e, arm, term_obs, ag_out, dg_out);
+    if (arm == 0) {
+        rew_out[e] = reward;
+        done_out[e] = done ? 1 : 0;
+        succ_out[e] = success ? 1 : 0;
+        if (done && P.auto_reset) {
+            const int pos = atomicAdd(done_count, 1);
+            done_list[pos] = (int)e;
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                 float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
+    const int arm = (int)(t & 1);
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (i >= n) return;
+    const int64_t e = list ? (int64_t)list[i] : i;
+    DevLds lds{smem + threadIdx.x};
+    xh::Lane<float> L;
+    ho_load(P, e, arm, L);
+    xh::lane_reset<float, DevLds, DppXchg>(P.hcfg, e, L, arm, lds, DppXchg());
+    ho_store(P, e, arm, L);
+    if (obs_out) ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+}
+__global__ void k_ho_compute_reward(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = ag[i * 3] - g[i * 3], dy = ag[i * 3 + 1] - g[i * 3 + 1], dz = ag[i * 3 + 2] - g[i * 3 + 2];
+    out[i] = sqrtf(dx * dx + dy * dy + dz * dz) > (float)xm::HO_DISTANCE_THRESHOLD ? -1.f : 0.f;
+}
+
 // number of steps taken in the current episode (info['future_length'] = max_episode_steps - steps, :90)
 __global__ void k_episode_steps(KParams P, int steps_field, int32_t *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -341,9 +465,10 @@ const char *xarm_last_error(const xarm_handle *h) { return h ? h->err : g_err; }
 
 int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (!cfg || !out) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: null argument");
-    const bool reach = cfg->env_kind == XARM_ENV_REACH;
-    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
+    const bool reach = cfg->env_kind == XARM_ENV_REACH, handover = cfg->env_kind == XARM_ENV_HANDOVER;
+    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach && !handover) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
     if (!reach && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
+    if (handover && cfg->reward_type != 0) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover is sparse-only (reward_type is hard-wired, xarm_handover.py:40)");
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
     if (cfg->reward_type < 0 || cfg->reward_type > 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
     if (!reach && cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
@@ -366,7 +491,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.cfg.goal_shape = cfg->goal_shape;
     h->kp.cfg.reward_type = cfg->reward_type;
     h->kp.auto_reset = cfg->auto_reset;
-    h->kp.state_dim = reach ? xr::STATE_DIM : xk::STATE_DIM;
+    h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : xk::STATE_DIM);
+    h->kp.hcfg.seed = cfg->seed;
+    h->kp.hcfg.env_id_offset = cfg->env_id_offset;
+    h->kp.hcfg.same_side_rate = cfg->same_side_rate;
+    h->kp.hcfg.goal_shape = cfg->goal_shape;
     h->kp.rcfg.seed = cfg->seed;
     h->kp.rcfg.env_id_offset = cfg->env_id_offset;
     h->kp.rcfg.reward_type = cfg->reward_type;
@@ -383,6 +512,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     hipMemset(h->done_count, 0, sizeof(int) * 2);
     hipMemset(h->mask_count, 0, sizeof(int));
     if (reach) k_reach_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
+    else if (handover) k_ho_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
     else k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
     hipError_t e5 = hipDeviceSynchronize();
     if (e5 != hipSuccess) {
@@ -409,13 +539,13 @@ int xarm_destroy(xarm_handle *h) {
 
 int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
     if (!out) return XARM_E_INVALID;
-    const bool reach = h && h->cfg.env_kind == XARM_ENV_REACH;
-    out->obs_dim = reach ? xr::OBS_DIM : xk::OBS_DIM;
+    const bool reach = h && h->cfg.env_kind == XARM_ENV_REACH, handover = h && h->cfg.env_kind == XARM_ENV_HANDOVER;
+    out->obs_dim = reach ? xr::OBS_DIM : (handover ? xh::OBS_DIM : xk::OBS_DIM);
     out->goal_dim = xk::GOAL_DIM;
-    out->act_dim = xk::ACT_DIM;
-    out->state_dim = reach ? xr::STATE_DIM : xk::STATE_DIM;
-    out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS;
-    out->n_substeps = reach ? xmr::N_SUBSTEPS : xm::PNP_N_SUBSTEPS;
+    out->act_dim = handover ? xh::ACT_DIM : xk::ACT_DIM;
+    out->state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : xk::STATE_DIM);
+    out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : (handover ? xm::HO_MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS);
+    out->n_substeps = reach ? xmr::N_SUBSTEPS : (handover ? xm::HO_N_TICKS : xm::PNP_N_SUBSTEPS);
     return XARM_OK;
 }
 
@@ -428,9 +558,11 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
         HIPCHK(h, hipMemsetAsync(h->mask_count, 0, sizeof(int), st));
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
     } else {
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
     }
     HIPCHK(h, hipGetLastError());
@@ -448,8 +580,11 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     const bool timed = h->timing && h->ev_created;
     if (timed && h->ev_n == xarm_handle::NEV) timing_flush(h);
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
-    const bool reach = h->cfg.env_kind == XARM_ENV_REACH;
-    if (reach)
+    const bool reach = h->cfg.env_kind == XARM_ENV_REACH, handover = h->cfg.env_kind == XARM_ENV_HANDOVER;
+    if (handover)
+        k_ho_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                       terminal_obs_dev, h->done_list, cnt, stale);
+    else if (reach)
         k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                       terminal_obs_dev, h->done_list, cnt, stale);
     else
@@ -458,6 +593,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
     if (h->kp.auto_reset) {
         if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else if (handover) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
     }
     h->step_index++;
@@ -468,6 +604,12 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
 int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
     if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
+    if (h->cfg.env_kind == XARM_ENV_HANDOVER) {
+        if (n == 0) return XARM_OK;
+        k_ho_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
+        HIPCHK(h, hipGetLastError());
+        return XARM_OK;
+    }
     if (h->cfg.env_kind == XARM_ENV_REACH) {
         if (h->cfg.reward_type == XARM_REACH_REWARD_DENSE_DIFF)
             return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense_diff' is stateful (d_old) and cannot be relabelled");
@@ -501,7 +643,7 @@ int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
 
 int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
     if (!h || !steps_dev) return XARM_E_INVALID;
-    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (int)xk::S_STEPS;
+    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (int)xh::H_STEPS : (int)xk::S_STEPS);
     k_episode_steps<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, field, steps_dev);
     HIPCHK(h, hipGetLastError());
     return XARM_OK;

@@ -1,2 +1,3 @@
 from .xarm_pick_and_place import XarmPickAndPlace  # noqa: F401
 from .xarm_reach import XarmReachEnv  # noqa: F401
+from .xarm_handover import XarmHandover  # noqa: F401

@@ -49,7 +49,7 @@ class XarmPickAndPlaceVecEnv:
                                   int(self.config["num_obj"]), _native.REWARD_TYPES[self.config["reward_type"]],
                                   _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
                                   float(self.config["goal_ground_rate"]), int(self._auto_reset),
-                                  self.device.index if self.device.index is not None else torch.cuda.current_device())
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0, 0)
 
     def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True):
         cfg = self._check_config(config)
@@ -260,12 +260,45 @@ class XarmReachVecEnv(XarmPickAndPlaceVecEnv):
     def _native_config(self):
         return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 0,
                                   _native.REACH_REWARD_TYPES[self.config["reward_type"]], 0, 0.0, 0.0, int(self._auto_reset),
-                                  self.device.index if self.device.index is not None else torch.cuda.current_device())
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0, 0)
 
     def _extra_info(self, info):
         # with auto-reset, finished envs already report the fresh episode's counter
         info["future_length"] = self._max_episode_steps - self.episode_steps()
         info["TimeLimit.truncated"] = self._done != 0   # Reach ends only by the step count (:93)
+
+    def debug_substeps(self, q_target, n):
+        raise NotImplementedError
+
+
+# test.py:9-15 of the reference drives XarmHandover-v0 with exactly these keys
+HANDOVER_CONFIG_DEFAULTS = {"GUI": False, "num_obj": 1, "same_side_rate": 0.5, "goal_shape": "ground", "use_stand": False}
+
+
+class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
+    """E independent XarmHandover-v0 environments (/root/reference/gym_xarm/envs/xarm_handover.py:19): two xArm7 +
+    Panda-gripper arms, one stick, two tables with a gap; obs 29 (:325-329), action 8 (:118), sparse reward
+    -[d > 0.05] (:177-183), done = success or 100 steps (:138 + registry).  num_obj = 1, use_stand = False."""
+
+    ENV_KIND = _native.ENV_HANDOVER
+
+    def _check_config(self, config):
+        cfg = dict(HANDOVER_CONFIG_DEFAULTS)
+        cfg.update(config or {})
+        if cfg["num_obj"] != 1:
+            raise NotImplementedError("this build supports num_obj == 1")
+        if cfg["use_stand"]:
+            raise NotImplementedError("use_stand=True (a static stand under the goal) is not built")
+        cfg.setdefault("reward_type", "sparse")
+        if cfg["reward_type"] != "sparse":
+            raise NotImplementedError("XarmHandover hard-wires reward_type='sparse' (xarm_handover.py:40)")
+        return cfg
+
+    def _native_config(self):
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 1, 0,
+                                  1 if self.config["goal_shape"] == "ground" else 0, 0.0, 0.0, int(self._auto_reset),
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(),
+                                  float(self.config["same_side_rate"]), 0)
 
     def debug_substeps(self, q_target, n):
         raise NotImplementedError

@@ -39,6 +39,9 @@ extern "C" {
 #define XARM_ENV_PICK_AND_PLACE 0 /* XarmPickAndPlace-v1 / XarmPDPickAndPlace-v0 (xarm_pick_and_place.py) */
 #define XARM_ENV_REACH 1          /* XarmReach-v0 (xarm_reach.py): obs 8, 25 steps, 20 substeps of 1/4800 s;
                                      xarm_config.num_obj / goal_shape / *_rate are ignored */
+#define XARM_ENV_HANDOVER 2       /* XarmHandover-v0 / XarmPDHandover-v0 (xarm_handover.py): two arms, one stick,
+                                     obs 29, action 8, sparse reward -1/0, 100 steps; uses same_side_rate and
+                                     goal_shape (XARM_GOAL_GROUND = 'ground', else the sampled height) */
 
 #define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
 #define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */
@@ -65,6 +68,8 @@ typedef struct xarm_config {
     float goal_ground_rate; /* config['goal_ground_rate'] */
     int32_t auto_reset;     /* 1: envs that finish an episode in xarm_step are reset in the same call */
     int32_t device;         /* HIP device ordinal */
+    float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
+    int32_t reserved;
 } xarm_config;
 
 typedef struct xarm_dims_t {

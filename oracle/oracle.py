@@ -65,6 +65,20 @@ REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
 REACH_STATE_DIM, REACH_OBS_DIM = 45, 8
 
 
+class XoHoCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("same_side_rate", _d), ("goal_shape", _i), ("n_ticks", _i),
+                ("time_step", _d), ("action_dt", _d), ("max_vel", _d), ("max_gripper_vel", _d),
+                ("pos_low", (_d * 3) * 2), ("pos_high", (_d * 3) * 2), ("goal_low", _d * 3), ("goal_high", _d * 3),
+                ("obj_low", _d * 2), ("obj_high", _d * 2), ("gripper_low", _d), ("gripper_high", _d), ("height_offset", _d),
+                ("eff_init_pos", (_d * 3) * 2), ("joint_init_pos", _d * 9), ("base_pos", (_d * 3) * 2), ("base_yaw", _d * 2),
+                ("finger_motor_force", _d), ("distance_threshold", _d), ("obj_half", _d * 3), ("eef2grip", _d * 3),
+                ("table_x_min", _d), ("table_x_max", _d), ("table_half_y", _d), ("ground_z", _d),
+                ("reset_ticks", _i), ("max_episode_steps", _i)]
+
+
+HO_STATE_DIM, HO_OBS_DIM, HO_ACT_DIM = 76, 29, 8
+
+
 class XoPnpCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("init_grasp_rate", _d),
                 ("goal_ground_rate", _d), ("goal_shape", _i), ("reward_type", _i)]
@@ -146,6 +160,11 @@ def lib():
         L.xo_pnp_compute_reward.argtypes = [mp, _i, C.c_int64, dp, dp, dp]
         L.xo_pnp_dense_reward.argtypes = [mp, _i, dp, dp, dp]
         L.xo_pnp_dense_reward.restype = _d
+        hp = C.POINTER(XoHoCfg)
+        L.xo_ho_init.argtypes = [mp, hp, C.c_int64, dp]
+        L.xo_ho_reset.argtypes = [mp, hp, C.c_int64, dp, u8p, dp, dp, dp]
+        L.xo_ho_step.argtypes = [mp, hp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
+        L.xo_ho_compute_reward.argtypes = [hp, C.c_int64, dp, dp, dp]
         rp = C.POINTER(XoReachCfg)
         L.xo_reach_init.argtypes = [mp, rp, C.c_int64, dp]
         L.xo_reach_reset.argtypes = [mp, rp, C.c_int64, dp, u8p, dp, dp, dp]
@@ -271,6 +290,64 @@ class OracleReach:
 
     def set_state(self, s):
         self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, REACH_STATE_DIM)
+
+
+class OracleHandover:
+    """Batched CPU XarmHandover-v0 (xarm_handover.py, num_obj = 1, use_stand False), float64."""
+
+    def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground"):
+        self.L = lib()
+        js = load_model_json()
+        self.m = build_model(js)
+        h = js["handover"]
+        c = XoHoCfg()
+        c.seed, c.env_id_offset, c.same_side_rate = seed, env_id_offset, same_side_rate
+        c.goal_shape = 1 if goal_shape == "ground" else 0
+        for k in ("n_ticks", "time_step", "action_dt", "max_vel", "max_gripper_vel", "gripper_low", "gripper_high", "height_offset",
+                  "finger_motor_force", "distance_threshold", "table_x_min", "table_x_max", "table_half_y", "ground_z",
+                  "reset_ticks", "max_episode_steps"):
+            setattr(c, k, h[k])
+        for k in ("pos_low", "pos_high", "eff_init_pos", "base_pos"):
+            for a in range(2):
+                for i in range(3):
+                    getattr(c, k)[a][i] = h[k][a][i]
+        for k, n in (("goal_low", 3), ("goal_high", 3), ("obj_low", 2), ("obj_high", 2), ("joint_init_pos", 9), ("base_yaw", 2),
+                     ("obj_half", 3), ("eef2grip", 3)):
+            for i in range(n):
+                getattr(c, k)[i] = h[k][i]
+        self.cfg = c
+        self.E = int(num_envs)
+        self.state = np.zeros((self.E, HO_STATE_DIM))
+        self.L.xo_ho_init(self.m, self.cfg, self.E, _p(self.state))
+
+    def _bufs(self):
+        return np.zeros((self.E, HO_OBS_DIM)), np.zeros((self.E, 3)), np.zeros((self.E, 3))
+
+    def reset(self, mask=None):
+        obs, ag, dg = self._bufs()
+        mk = None if mask is None else _u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xo_ho_reset(self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
+        return obs, ag, dg
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.E, HO_ACT_DIM)
+        obs, ag, dg = self._bufs()
+        rew, done, succ = np.zeros(self.E), np.zeros(self.E, np.uint8), np.zeros(self.E, np.uint8)
+        self.L.xo_ho_step(self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg), _p(rew), _u8(done), _u8(succ))
+        return obs, ag, dg, rew, done, succ
+
+    def compute_reward(self, ag, g):
+        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, 3)
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(ag.shape[0])
+        self.L.xo_ho_compute_reward(self.cfg, ag.shape[0], _p(ag), _p(g), _p(out))
+        return out
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, s):
+        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, HO_STATE_DIM)
 
 
 def dense_reward(if_grasp, hand_com, ag, g, model=None):

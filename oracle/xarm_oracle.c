@@ -166,10 +166,13 @@ typedef struct {
     real S[XO_MAXL][6];    /* joint motion subspace, link coords */
     real I[XO_MAXL][36];   /* link spatial inertia, link coords */
     real IA[XO_MAXL][36], U[XO_MAXL][6], D[XO_MAXL]; /* ABA cache (depends on q only) */
+    real Rbase[9], pbase[3]; /* fixed base pose in the world (identity for the single-arm envs) */
 } tree_t;
 
-static void tree_setup(const xo_model *m, const real *q, tree_t *t) {
+static void tree_setup_base(const xo_model *m, const real *q, tree_t *t, const real *Rbase, const real *pbase) {
     int nd = 0;
+    if (Rbase) { memcpy(t->Rbase, Rbase, 9 * sizeof(real)); v3_copy(t->pbase, pbase); }
+    else { m3_ident(t->Rbase); v3_set(t->pbase, 0, 0, 0); }
     for (int i = 0; i < m->n_links; i++) t->dof[i] = (m->jtype[i] != 0) ? nd++ : -1;
     t->nd = nd;
     for (int i = 0; i < m->n_links; i++) {
@@ -203,8 +206,10 @@ static void tree_setup(const xo_model *m, const real *q, tree_t *t) {
         /* world frames */
         int p = m->parent[i];
         if (p < 0) {
-            memcpy(t->R[i], Rpc, sizeof Rpc);
-            v3_copy(t->o[i], r);
+            real rw[3];
+            m3_mul(t->R[i], t->Rbase, Rpc);
+            m3_vec(rw, t->Rbase, r);
+            v3_add(t->o[i], t->pbase, rw);
         } else {
             m3_mul(t->R[i], t->R[p], Rpc);
             real rw[3];
@@ -230,6 +235,8 @@ static void tree_setup(const xo_model *m, const real *q, tree_t *t) {
         for (int a = 0; a < 3; a++) t->I[i][(a + 3) * 6 + a + 3] = mass;
     }
 }
+
+static void tree_setup(const xo_model *m, const real *q, tree_t *t) { tree_setup_base(m, q, t, 0, 0); }
 
 /* Featherstone articulated-body algorithm (RBDA Table 7.1), fixed base, link coordinates.
  * Restates btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof. */
@@ -279,7 +286,8 @@ static void aba_forward_dynamics(const xo_model *m, tree_t *t, const real *qd, c
             for (int k = 0; k < 6; k++) pA[p][k] += Xtp[k];
         }
     }
-    real a0[6] = {0, 0, 0, 0, 0, g}; /* base accelerates upward = gravity pulls down */
+    real a0[6] = {0, 0, 0, 0, 0, 0}, gw[3] = {0, 0, g}; /* base accelerates upward = gravity pulls down */
+    m3_tvec(a0 + 3, t->Rbase, gw);                     /* expressed in base axes */
     for (int i = 0; i < n; i++) {
         int p = m->parent[i];
         real ap[6];
@@ -382,15 +390,16 @@ static void rot_error_vec(const real *Rt, const real *Rc, real *e) {
     }
 }
 
-static void ik_solve(const xo_model *m, const real *q_in, const real *target, int max_iter, real *q_out) {
+static void ik_solve_base(const xo_model *m, const real *q_in, const real *target, int max_iter, real *q_out,
+                          const real *Rbase, const real *pbase) {
     real q[XO_MAXD];
     tree_t t;
-    const real Rt[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1}; /* quaternion (1,0,0,0) */
+    const real Rt[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1}; /* quaternion (1,0,0,0), world frame */
     int e = m->eef_link;
-    tree_setup(m, q_in, &t);
+    tree_setup_base(m, q_in, &t, Rbase, pbase);
     memcpy(q, q_in, t.nd * sizeof(real));
     for (int it = 0; it < max_iter; it++) {
-        if (it > 0) tree_setup(m, q, &t);
+        if (it > 0) tree_setup_base(m, q, &t, Rbase, pbase);
         real err[6];
         v3_sub(err, target, t.o[e]);
         if (v3_norm(err) < m->ik_residual) break;
@@ -446,6 +455,9 @@ static void ik_solve(const xo_model *m, const real *q_in, const real *target, in
     }
     memcpy(q_out, q, t.nd * sizeof(real));
 }
+static void ik_solve(const xo_model *m, const real *q_in, const real *target, int max_iter, real *q_out) {
+    ik_solve_base(m, q_in, target, max_iter, q_out, 0, 0);
+}
 
 static int dof_of_link(const xo_model *m, int link) {
     int nd = 0;
@@ -464,6 +476,7 @@ typedef struct {
     real vt, cfm, inv_d, lo, hi, lam;
     int normal_row; /* index of the normal row whose impulse bounds this friction row, or -1 */
     real mu;
+    int arm;        /* which arm the joint-space part belongs to (dual-arm envs), 0 otherwise */
 } row_t;
 #define XO_MAXROWS 96
 
@@ -482,7 +495,7 @@ static void plane_space(const real *n, real *p, real *q) {
 
 typedef struct {
     const xo_model *m;
-    tree_t t;
+    tree_t t, t2; /* t2: second arm of the dual-arm envs */
     real Rb[9], Iinv_w[9];
     row_t rows[XO_MAXROWS];
     int nrows;
@@ -491,8 +504,9 @@ typedef struct {
 static void row_finish(solver_t *s, row_t *r) {
     real d = 0;
     if (r->has_a) {
-        aba_impulse_response(s->m, &s->t, r->Ja, r->Ba);
-        for (int k = 0; k < s->t.nd; k++) d += r->Ja[k] * r->Ba[k];
+        const tree_t *t = r->arm ? &s->t2 : &s->t;
+        aba_impulse_response(s->m, t, r->Ja, r->Ba);
+        for (int k = 0; k < t->nd; k++) d += r->Ja[k] * r->Ba[k];
     }
     if (r->has_b) {
         real w[3];
@@ -511,8 +525,8 @@ static row_t *row_new(solver_t *s) {
 }
 /* three rows (normal, 2 x friction) of one contact point.  The normal points from body B to
  * body A; link >= 0: A is that arm link and B the object; link < 0: A is the object, B static. */
-static int add_contact(solver_t *s, int link, const real *p, const real *n, real dist, real dt, real erp,
-                       real cfm, real mu, real lam0, const real *cb) {
+static int add_contact_arm(solver_t *s, int arm, int link, const real *p, const real *n, real dist, real dt, real erp,
+                           real cfm, real mu, real lam0, const real *cb) {
     real t1[3], t2[3], r[3];
     plane_space(n, t1, t2);
     v3_sub(r, p, cb);
@@ -527,7 +541,8 @@ static int add_contact(solver_t *s, int link, const real *p, const real *n, real
         for (int c = 0; c < 3; c++) { row->Jb[c] = sgn * dirs[k][c]; row->Jb[c + 3] = sgn * rxd[c]; }
         if (link >= 0) {
             row->has_a = 1;
-            point_jacobian_row(s->m, &s->t, link, p, dirs[k], row->Ja);
+            row->arm = arm;
+            point_jacobian_row(s->m, arm ? &s->t2 : &s->t, link, p, dirs[k], row->Ja);
         }
         if (k == 0) {
             row->vt = dist < 0 ? -erp * dist / dt : -dist / dt;
@@ -541,6 +556,11 @@ static int add_contact(solver_t *s, int link, const real *p, const real *n, real
         row_finish(s, row);
     }
     return nrow;
+}
+
+static int add_contact(solver_t *s, int link, const real *p, const real *n, real dist, real dt, real erp,
+                       real cfm, real mu, real lam0, const real *cb) {
+    return add_contact_arm(s, 0, link, p, n, dist, dt, erp, cfm, mu, lam0, cb);
 }
 
 static void apply_row_impulse(const row_t *r, real dl, real *qd, real *vb, int nd) {
@@ -1136,6 +1156,349 @@ int xo_reach_step(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double 
         else { reward[e] = st[R_DOLD] - dist; st[R_DOLD] = dist; } /* :113-116 */
         done[e] = (uint8_t)((int)st[R_STEPS] == cfg->max_episode_steps); /* :93 */
         if (future_length) future_length[e] = cfg->max_episode_steps - (int)st[R_STEPS]; /* :90 */
+    }
+    return 0;
+}
+
+/* ==================================================================================== XarmHandover-v0
+ * /root/reference/gym_xarm/envs/xarm_handover.py: step :128-139, _set_action :244-297, _get_obs :299-336,
+ * reset/_reset_sim/_sample_goal :141-145,338-393, compute_reward (sparse) :164-183, _is_success :395-402.
+ * Two xarm7_pd arms (bases at x = -+0.6, the second yawed by pi, :50-53,95-96), one 0.15 x 0.05 x 0.05 stick
+ * (:89-92), two tables with a 0.2 m gap over a ground plane at z = -0.625 (:79-83); timeStep 1/240 with the
+ * default single substep, 15 stepSimulation calls per env step (:28-29,131-132).  num_obj = 1, use_stand False. */
+enum { H_Q = 0, H_QD = 18, H_FT = 36, H_BP = 38, H_BQ = 41, H_BV = 45, H_BW = 48, H_GOAL = 51, H_LT = 54, H_LP = 62,
+       H_TOUCH = 70, H_MUG = 72, H_STEPS = 74, H_EPISODE = 75 };
+
+static void ho_base(const xo_ho_cfg *c, int arm, real *R, real *p) {
+    real rpy[3] = {0, 0, c->base_yaw[arm]};
+    m3_from_rpy(R, rpy);
+    v3_copy(p, c->base_pos[arm]);
+}
+
+static void ho_substep(const xo_model *m, const xo_ho_cfg *c, real *st, const real qt[2][XO_MAXD], real dt) {
+    static const real finger_sign[2] = {1.0, -1.0};
+    solver_t s;
+    s.m = m;
+    s.nrows = 0;
+    tree_t *tr[2] = {&s.t, &s.t2};
+    for (int a = 0; a < 2; a++) {
+        real Rb[9], pb[3];
+        ho_base(c, a, Rb, pb);
+        tree_setup_base(m, st + H_Q + 9 * a, tr[a], Rb, pb);
+    }
+    real *bp = st + H_BP, *bq = st + H_BQ;
+    real vb[6] = {st[H_BV], st[H_BV + 1], st[H_BV + 2], st[H_BW], st[H_BW + 1], st[H_BW + 2]};
+    quat_to_m3(s.Rb, bq);
+    const real *h = c->obj_half;
+    real Ib[3] = {m->obj_mass / 3.0 * (h[1] * h[1] + h[2] * h[2]), m->obj_mass / 3.0 * (h[0] * h[0] + h[2] * h[2]),
+                  m->obj_mass / 3.0 * (h[0] * h[0] + h[1] * h[1])};
+    for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 3; cc++) {
+            real v = 0;
+            for (int k = 0; k < 3; k++) v += s.Rb[r * 3 + k] * s.Rb[cc * 3 + k] / Ib[k];
+            s.Iinv_w[r * 3 + cc] = v;
+        }
+    /* unconstrained motion */
+    for (int a = 0; a < 2; a++) {
+        real tau[XO_MAXD] = {0}, qdd[XO_MAXD], *qd = st + H_QD + 9 * a;
+        for (int i = 0; i < m->n_links; i++)
+            if (tr[a]->dof[i] >= 0) tau[tr[a]->dof[i]] = -m->damping[i] * qd[tr[a]->dof[i]];
+        aba_forward_dynamics(m, tr[a], qd, tau, m->gravity, qdd);
+        for (int k = 0; k < 9; k++) qd[k] += dt * qdd[k];
+    }
+    {
+        real wl[3], Iw[3], g[3], gw[3], dw[3];
+        m3_tvec(wl, s.Rb, vb + 3);
+        v3_set(Iw, Ib[0] * wl[0], Ib[1] * wl[1], Ib[2] * wl[2]);
+        v3_cross(g, Iw, wl);
+        m3_vec(gw, s.Rb, g);
+        m3_vec(dw, s.Iinv_w, gw);
+        v3_axpy(vb + 3, dt, dw);
+        vb[2] -= dt * m->gravity;
+        real dl = pow(1.0 - m->lin_damping, dt), da = pow(1.0 - m->ang_damping, dt);
+        for (int k = 0; k < 3; k++) { vb[k] *= dl; vb[k + 3] *= da; }
+    }
+    real *lam_t = st + H_LT, *lam_p = st + H_LP;
+    int row_t_n[8], row_p_n[8], n_table = 0;
+    /* (T) stick corners against the table tops (z = 0) or, over the gap / beside the tables, the ground plane */
+    for (int i = 0; i < 8; i++) {
+        real rl[3] = {(i & 1) ? h[0] : -h[0], (i & 2) ? h[1] : -h[1], (i & 4) ? h[2] : -h[2]}, r[3], p[3];
+        m3_vec(r, s.Rb, rl);
+        v3_add(p, bp, r);
+        int on_table = fabs(p[0]) >= c->table_x_min && fabs(p[0]) <= c->table_x_max && fabs(p[1]) <= c->table_half_y;
+        real dist = p[2] - (on_table ? m->table_top_z : c->ground_z);
+        int active = dist < m->solver_margin && n_table < 4;
+        row_t_n[i] = -1;
+        if (!active) { lam_t[i] = 0; continue; }
+        n_table++;
+        real n[3] = {0, 0, 1};
+        row_t_n[i] = add_contact_arm(&s, 0, -1, p, n, dist, dt, m->contact_erp, 0.0, m->mu_object * m->mu_table,
+                                     m->warmstart * lam_t[i], bp);
+    }
+    /* (M)(L)(G) per arm */
+    for (int a = 0; a < 2; a++) {
+        real *q = st + H_Q + 9 * a, *qd = st + H_QD + 9 * a;
+        for (int i = 0; i < m->n_links; i++) {
+            if (tr[a]->dof[i] < 0) continue;
+            int d = tr[a]->dof[i];
+            row_t *r = row_new(&s);
+            r->has_a = 1; r->arm = a;
+            r->Ja[d] = 1;
+            r->vt = m->motor_kp * (qt[a][d] - q[d]) / dt + (1.0 - m->motor_kd) * qd[d];
+            real force = (m->jtype[i] == 2) ? c->finger_motor_force : m->arm_motor_force;
+            r->hi = force * c->time_step;
+            r->lo = -r->hi;
+            row_finish(&s, r);
+        }
+        for (int i = 0; i < m->n_links; i++) {
+            if (tr[a]->dof[i] < 0) continue;
+            int d = tr[a]->dof[i];
+            for (int side = 0; side < 2; side++) {
+                real gap = side == 0 ? q[d] - m->lower[i] : m->upper[i] - q[d];
+                if (gap >= m->limit_window) continue;
+                row_t *r = row_new(&s);
+                r->has_a = 1; r->arm = a;
+                r->Ja[d] = side == 0 ? 1.0 : -1.0;
+                r->vt = gap < 0 ? -m->global_erp * gap / dt : -gap / dt;
+                r->lo = 0; r->hi = 1e30;
+                row_finish(&s, r);
+            }
+        }
+        {
+            int d1 = tr[a]->dof[m->finger_link[0]], d2 = tr[a]->dof[m->finger_link[1]];
+            row_t *r = row_new(&s);
+            r->has_a = 1; r->arm = a;
+            r->Ja[d1] = 1.0;
+            r->Ja[d2] = -1.0;
+            r->vt = -m->gear_erp * m->global_erp * (q[d1] - q[d2]) / dt;
+            r->hi = m->gear_max_force * c->time_step;
+            r->lo = -r->hi;
+            row_finish(&s, r);
+        }
+    }
+    /* (F) pads of arm 0, then of arm 1, against the stick */
+    {
+        real denom = dt * m->finger_contact_stiffness + m->finger_contact_damping + m->object_contact_damping;
+        real cfm = (1.0 / denom) / dt, erp = dt * m->finger_contact_stiffness / denom;
+        for (int a = 0; a < 2; a++) {
+            int touch[2] = {0, 0};
+            real mu = m->mu_object * (st[H_MUG + a] > 0.5 ? m->mu_finger_grasp : m->mu_finger);
+            for (int f = 0; f < 2; f++) {
+                int l = m->finger_link[f];
+                for (int j = 0; j < XO_NPAD; j++) {
+                    real cl[3] = {m->pad_center_left[j][0], finger_sign[f] * m->pad_center_left[j][1], m->pad_center_left[j][2]};
+                    real cw[3], dist, n[3], p[3];
+                    m3_vec(cw, tr[a]->R[l], cl);
+                    v3_add(cw, cw, tr[a]->o[l]);
+                    int idx = a * 4 + f * XO_NPAD + j;
+                    row_p_n[idx] = -1;
+                    if (sphere_box(cw, m->pad_radius, bp, s.Rb, h, m->contact_margin, &dist, n, p)) touch[f] = 1;
+                    if (!(dist < m->solver_margin)) { lam_p[idx] = 0; continue; }
+                    row_p_n[idx] = add_contact_arm(&s, a, l, p, n, dist, dt, erp, cfm, mu, m->warmstart * lam_p[idx], bp);
+                }
+            }
+            st[H_TOUCH + a] = (touch[0] && touch[1]) ? 1.0 : 0.0;
+        }
+    }
+    /* warm start + PGS */
+    for (int k = 0; k < s.nrows; k++)
+        if (s.rows[k].lam != 0) apply_row_impulse(&s.rows[k], s.rows[k].lam, st + H_QD + 9 * s.rows[k].arm, vb, 9);
+    for (int it = 0; it < m->num_iterations; it++)
+        for (int k = 0; k < s.nrows; k++) {
+            row_t *r = &s.rows[k];
+            real *qd = st + H_QD + 9 * r->arm;
+            if (r->normal_row >= 0) {
+                real lim = r->mu * s.rows[r->normal_row].lam;
+                r->lo = -lim; r->hi = lim;
+            }
+            real jv = 0;
+            if (r->has_a) for (int cc = 0; cc < 9; cc++) jv += r->Ja[cc] * qd[cc];
+            if (r->has_b) for (int cc = 0; cc < 6; cc++) jv += r->Jb[cc] * vb[cc];
+            real dl = (r->vt - r->cfm * r->lam - jv) * r->inv_d, nl = r->lam + dl;
+            if (nl < r->lo) nl = r->lo;
+            if (nl > r->hi) nl = r->hi;
+            dl = nl - r->lam;
+            r->lam = nl;
+            apply_row_impulse(r, dl, qd, vb, 9);
+        }
+    for (int i = 0; i < 8; i++) {
+        if (row_t_n[i] >= 0) lam_t[i] = s.rows[row_t_n[i]].lam;
+        if (row_p_n[i] >= 0) lam_p[i] = s.rows[row_p_n[i]].lam;
+    }
+    for (int k = 0; k < 18; k++) st[H_Q + k] += dt * st[H_QD + k];
+    for (int k = 0; k < 3; k++) bp[k] += dt * vb[k];
+    {
+        real w[3] = {vb[3], vb[4], vb[5]}, ang = v3_norm(w), ax[3];
+        if (ang * dt > 0.7853981633974483) ang = 0.7853981633974483 / dt;
+        real k = ang < 0.001 ? 0.5 * dt - dt * dt * dt * 0.020833333333 * ang * ang : sin(0.5 * ang * dt) / ang;
+        v3_set(ax, w[0] * k, w[1] * k, w[2] * k);
+        real cw = cos(ang * dt * 0.5), x = bq[0], y = bq[1], z = bq[2], w0 = bq[3];
+        real nx = cw * x + ax[0] * w0 + ax[1] * z - ax[2] * y, ny = cw * y + ax[1] * w0 + ax[2] * x - ax[0] * z;
+        real nz = cw * z + ax[2] * w0 + ax[0] * y - ax[1] * x, nw = cw * w0 - ax[0] * x - ax[1] * y - ax[2] * z;
+        real inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+        bq[0] = nx * inv; bq[1] = ny * inv; bq[2] = nz * inv; bq[3] = nw * inv;
+    }
+    for (int k = 0; k < 3; k++) { st[H_BV + k] = vb[k]; st[H_BW + k] = vb[k + 3]; }
+}
+
+/* IK of one arm in the world frame (the arm's base pose enters through its forward kinematics) */
+static void ho_ik(const xo_model *m, const xo_ho_cfg *c, int arm, const real *q9, const real *target, real *q_out) {
+    /* world-frame DLS (the DLS step is invariant under a rotation of the task frame); target orientation
+     * quaternion (1,0,0,0) is given in the world frame (:257-258) */
+    real Rb[9], pb[3], qin[XO_MAXD] = {0};
+    ho_base(c, arm, Rb, pb);
+    memcpy(qin, q9, 9 * sizeof(real));
+    ik_solve_base(m, qin, target, c->n_ticks, q_out, Rb, pb);
+}
+static void ho_eef(const xo_model *m, const xo_ho_cfg *c, int arm, const real *q9, real *pos) {
+    tree_t t;
+    real Rb[9], pb[3], qin[XO_MAXD] = {0};
+    ho_base(c, arm, Rb, pb);
+    memcpy(qin, q9, 9 * sizeof(real));
+    tree_setup_base(m, qin, &t, Rb, pb);
+    v3_copy(pos, t.o[m->eef_link]);
+}
+static void ho_obs(const xo_model *m, const xo_ho_cfg *c, const real *st, real *obs, real *ag, real *dg) {
+    for (int k = 0; k < 3; k++) obs[k] = st[H_BP + k];
+    for (int k = 0; k < 4; k++) obs[3 + k] = st[H_BQ + k];
+    for (int k = 0; k < 3; k++) { obs[7 + k] = st[H_BV + k]; obs[10 + k] = st[H_BW + k]; }
+    for (int a = 0; a < 2; a++) {
+        tree_t t;
+        real Rb[9], pb[3], qin[XO_MAXD] = {0}, cm[3], hp[3];
+        ho_base(c, a, Rb, pb);
+        memcpy(qin, st + H_Q + 9 * a, 9 * sizeof(real));
+        tree_setup_base(m, qin, &t, Rb, pb);
+        int l = m->hand_link, d1 = t.dof[m->finger_link[0]];
+        m3_vec(cm, t.R[l], m->com[l]);
+        v3_add(hp, t.o[l], cm);
+        for (int k = 0; k < 3; k++) {
+            real dd[3] = {0, 0, 0}, J[XO_MAXD], sum = 0;
+            dd[k] = 1;
+            point_jacobian_row(m, &t, l, hp, dd, J);
+            for (int j = 0; j < 9; j++) sum += J[j] * st[H_QD + 9 * a + j];
+            obs[13 + 8 * a + k] = hp[k] - c->eef2grip[k];   /* :310-311 */
+            obs[13 + 8 * a + 3 + k] = sum;
+        }
+        obs[13 + 8 * a + 6] = st[H_Q + 9 * a + d1];
+        obs[13 + 8 * a + 7] = st[H_QD + 9 * a + d1];
+    }
+    for (int k = 0; k < 3; k++) { ag[k] = st[H_BP + k]; dg[k] = st[H_GOAL + k]; }
+}
+/* draws: 0-1 object xy, 2 mirror coin, 3-5 goal xyz, 6 same-side coin */
+static void ho_draws(const xo_ho_cfg *c, int64_t env, int64_t episode, real *u) {
+    uint32_t o[4];
+    uint64_t gid = (uint64_t)(c->env_id_offset + env);
+    for (int b = 0; b < 2; b++) {
+        xo_philox(c->seed, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)episode, (uint32_t)b, o);
+        for (int k = 0; k < 4; k++) u[b * 4 + k] = u01(o[k]);
+    }
+}
+static void ho_sample_object(const xo_ho_cfg *c, const real *u, real *st) {
+    real x = c->obj_low[0] + u[0] * (c->obj_high[0] - c->obj_low[0]);
+    st[H_BP] = u[2] < 0.5 ? -x : x;                                        /* :361-362 */
+    st[H_BP + 1] = c->obj_low[1] + u[1] * (c->obj_high[1] - c->obj_low[1]);
+    st[H_BP + 2] = c->height_offset;
+    st[H_BQ] = st[H_BQ + 1] = st[H_BQ + 2] = 0; st[H_BQ + 3] = 1;
+    for (int k = 0; k < 6; k++) st[H_BV + k] = 0;
+    for (int k = 0; k < 16; k++) st[H_LT + k] = 0;
+}
+static void ho_sample_goal(const xo_ho_cfg *c, const real *u, real *st) {
+    for (int k = 0; k < 3; k++) st[H_GOAL + k] = c->goal_low[k] + u[3 + k] * (c->goal_high[k] - c->goal_low[k]);
+    int same = u[6] < c->same_side_rate;
+    if ((st[H_BP] > 0) != same) st[H_GOAL] = -st[H_GOAL];                   /* (obj_x > 0) XOR same_side, :380-382 */
+    if (c->goal_shape == 1) st[H_GOAL + 2] = c->height_offset;
+}
+int xo_ho_init(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state) {
+    (void)m;
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_HO_STATE_DIM, u[8];
+        memset(st, 0, XO_HO_STATE_DIM * sizeof(real));
+        for (int a = 0; a < 2; a++) {
+            for (int k = 0; k < 9; k++) st[H_Q + 9 * a + k] = c->joint_init_pos[k];
+            st[H_FT + a] = c->joint_init_pos[7];
+        }
+        ho_draws(c, e, 0, u);
+        ho_sample_object(c, u, st);
+        ho_sample_goal(c, u, st);
+    }
+    return 0;
+}
+int xo_ho_reset(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state, const uint8_t *mask, double *obs,
+                double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        real *st = state + e * XO_HO_STATE_DIM, u[8], qt[2][XO_MAXD];
+        int64_t episode = (int64_t)st[H_EPISODE] + 1;
+        for (int k = 0; k <= c->reset_ticks; k++) {
+            if (k < c->reset_ticks) {
+                for (int a = 0; a < 2; a++) {
+                    ho_ik(m, c, a, st + H_Q + 9 * a, c->eff_init_pos[a], qt[a]);
+                    qt[a][7] = qt[a][8] = st[H_FT + a];     /* the finger motors keep their last targets */
+                }
+            } else {
+                ho_draws(c, e, episode, u);
+                ho_sample_object(c, u, st);
+            }
+            ho_substep(m, c, st, qt, c->time_step);          /* one stepSimulation, :353,365 */
+        }
+        ho_sample_goal(c, u, st);
+        st[H_STEPS] = 0;
+        st[H_EPISODE] = (real)episode;
+        if (obs) ho_obs(m, c, st, obs + e * XO_HO_OBS_DIM, ag + e * 3, dg + e * 3);
+    }
+    return 0;
+}
+int xo_ho_compute_reward(const xo_ho_cfg *c, int64_t n, const double *ag, const double *g, double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        real d[3];
+        v3_sub(d, ag + i * 3, g + i * 3);
+        out[i] = -(v3_norm(d) > c->distance_threshold ? 1.0 : 0.0);
+    }
+    return 0;
+}
+int xo_ho_step(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state, const double *actions, double *obs,
+               double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success) {
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_HO_STATE_DIM, qt[2][XO_MAXD];
+        const real *act = actions + e * XO_HO_ACT_DIM;
+        st[H_STEPS] += 1;
+        for (int a = 0; a < 2; a++) {
+            real av[4], cur[3], tgt[3];
+            for (int k = 0; k < 4; k++) { real v = act[a * 4 + k]; av[k] = v < -1 ? -1 : (v > 1 ? 1 : v); }   /* :129 */
+            ho_eef(m, c, a, st + H_Q + 9 * a, cur);
+            for (int k = 0; k < 3; k++) {
+                real v = cur[k] + av[k] * c->max_vel * c->action_dt;
+                tgt[k] = v < c->pos_low[a][k] ? c->pos_low[a][k] : (v > c->pos_high[a][k] ? c->pos_high[a][k] : v);
+            }
+            real g = st[H_Q + 9 * a + 7] + av[3] * c->action_dt * c->max_gripper_vel;
+            g = g < c->gripper_low ? c->gripper_low : (g > c->gripper_high ? c->gripper_high : g);
+            ho_ik(m, c, a, st + H_Q + 9 * a, tgt, qt[a]);
+            qt[a][7] = qt[a][8] = g;
+            st[H_FT + a] = g;
+            st[H_MUG + a] = st[H_TOUCH + a];     /* friction toggle from the current contact points, :269-280 */
+        }
+        /* clamp the stick into the play field, keep only its pitch, zero its velocity (:282-297) */
+        {
+            real x = st[H_BQ], y = st[H_BQ + 1], z = st[H_BQ + 2], w = st[H_BQ + 3];
+            real sarg = 2 * (w * y - x * z), pitch;
+            if (sarg <= -0.99999) pitch = -0.5 * 3.14159265358979323846;
+            else if (sarg >= 0.99999) pitch = 0.5 * 3.14159265358979323846;
+            else pitch = asin(sarg);
+            st[H_BQ] = 0; st[H_BQ + 1] = sin(0.5 * pitch); st[H_BQ + 2] = 0; st[H_BQ + 3] = cos(0.5 * pitch);
+            for (int k = 0; k < 2; k++) {
+                real v = st[H_BP + k], hi = c->obj_high[k];
+                st[H_BP + k] = v < -hi ? -hi : (v > hi ? hi : v);
+            }
+            for (int k = 0; k < 6; k++) st[H_BV + k] = 0;
+        }
+        for (int k = 0; k < c->n_ticks; k++) ho_substep(m, c, st, qt, c->time_step);
+        ho_obs(m, c, st, obs + e * XO_HO_OBS_DIM, ag + e * 3, dg + e * 3);
+        real d[3];
+        v3_sub(d, ag + e * 3, dg + e * 3);
+        real dist = v3_norm(d);
+        success[e] = (uint8_t)(dist < c->distance_threshold);
+        reward[e] = -(dist > c->distance_threshold ? 1.0 : 0.0);
+        done[e] = (uint8_t)(success[e] || ((int)st[H_STEPS] == c->max_episode_steps));
     }
     return 0;
 }

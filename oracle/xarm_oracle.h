@@ -122,6 +122,32 @@ int xo_reach_step(const xo_model *m, const xo_reach_cfg *cfg, int64_t E, double 
                   int32_t *future_length);
 int xo_reach_compute_reward(const xo_reach_cfg *cfg, int reward_type, int64_t n, const double *ag, const double *g,
                             double *out);
+/* ---- XarmHandover-v0 / XarmPDHandover-v0 (xarm_handover.py), two xarm7_pd arms + one stick ---- */
+#define XO_HO_STATE_DIM 76 /* q[2][9] qd[2][9] finger_target[2] obj_pos[3] obj_quat[4] obj_v[3] obj_w[3] goal[3]
+                              lam_table[8] lam_pad[2][4] touch[2] mu_grasp[2] num_steps episode */
+#define XO_HO_OBS_DIM 29
+#define XO_HO_ACT_DIM 8
+typedef struct {
+    uint64_t seed;
+    int64_t env_id_offset;
+    double same_side_rate;      /* config['same_side_rate'] */
+    int32_t goal_shape;         /* 1 = 'ground' (goal z = 0.025), anything else keeps the sampled z (:387-388) */
+    int32_t n_ticks;            /* python loop of stepSimulation per env step (:131) */
+    double time_step, action_dt, max_vel, max_gripper_vel;
+    double pos_low[2][3], pos_high[2][3], goal_low[3], goal_high[3], obj_low[2], obj_high[2];
+    double gripper_low, gripper_high, height_offset, eff_init_pos[2][3], joint_init_pos[9];
+    double base_pos[2][3], base_yaw[2];
+    double finger_motor_force, distance_threshold, obj_half[3], eef2grip[3];
+    double table_x_min, table_x_max, table_half_y, ground_z; /* tables cover table_x_min <= |x| <= table_x_max */
+    int32_t reset_ticks, max_episode_steps;
+} xo_ho_cfg;
+int xo_ho_init(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state);
+int xo_ho_reset(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,
+                double *ag, double *dg);
+int xo_ho_step(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const double *actions, double *obs,
+               double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success);
+/* sparse reward of xarm_handover.py:177-183 for N = 1 over n rows */
+int xo_ho_compute_reward(const xo_ho_cfg *cfg, int64_t n, const double *ag, const double *g, double *out);
 /* diagnostics used by tests */
 int xo_fk(const xo_model *m, const double *q, double *link_pos /*[n_links*3]*/,
           double *link_rot /*[n_links*9]*/);

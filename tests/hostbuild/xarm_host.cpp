@@ -7,6 +7,8 @@
 #define XARM_HOST_BUILD 1
 #include "../../gym_xarm_amd/csrc/xarm_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_reach_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_handover_core.h"
+#include <pthread.h>
 #include <string.h>
 
 namespace {
@@ -119,7 +121,102 @@ template <typename T> void reach_init(const xr::EnvCfg &c, int64_t E, double *st
 }
 }
 
+// ---- Handover: the two lanes of an environment run as two host threads, the lane-pair exchange is a slot + barrier
+namespace {
+struct PairShared { pthread_barrier_t bar; double slot[2]; };
+struct PairXchg {
+    PairShared *sh; int arm;
+    template <typename T> T get(int src, T v) const {
+        sh->slot[arm] = (double)v;
+        pthread_barrier_wait(&sh->bar);
+        T r = (T)sh->slot[src];
+        pthread_barrier_wait(&sh->bar);
+        return r;
+    }
+    template <typename T> T from0(T v) const { return get(0, v); }
+    template <typename T> T from1(T v) const { return get(1, v); }
+    template <typename T> T partner(T v) const { return get(1 - arm, v); }
+};
+template <typename T> void hload(const double *r, int arm, xh::Lane<T> &L) {
+    for (int i = 0; i < 9; i++) { L.st.q[i] = (T)r[xh::H_Q + 9 * arm + i]; L.st.qd[i] = (T)r[xh::H_QD + 9 * arm + i]; }
+    L.ft = (T)r[xh::H_FT + arm];
+    for (int i = 0; i < 3; i++) { L.st.bp[i] = (T)r[xh::H_BP + i]; L.st.bv[i] = (T)r[xh::H_BV + i]; L.st.bw[i] = (T)r[xh::H_BW + i]; L.st.goal[i] = (T)r[xh::H_GOAL + i]; }
+    for (int i = 0; i < 4; i++) L.st.bq[i] = (T)r[xh::H_BQ + i];
+    for (int i = 0; i < 8; i++) { L.st.lam_t[i] = (T)r[xh::H_LT + i]; L.st.lam_p[i] = i < 4 ? (T)r[xh::H_LP + 4 * arm + i] : (T)0; }
+    L.st.touch = (T)r[xh::H_TOUCH + arm]; L.st.mug = (T)r[xh::H_MUG + arm]; L.st.steps = (T)r[xh::H_STEPS]; L.st.episode = (T)r[xh::H_EPISODE];
+}
+template <typename T> void hstore(const xh::Lane<T> &L, int arm, double *r) {
+    for (int i = 0; i < 9; i++) { r[xh::H_Q + 9 * arm + i] = L.st.q[i]; r[xh::H_QD + 9 * arm + i] = L.st.qd[i]; }
+    r[xh::H_FT + arm] = L.ft;
+    for (int i = 0; i < 4; i++) r[xh::H_LP + 4 * arm + i] = L.st.lam_p[i];
+    r[xh::H_TOUCH + arm] = L.st.touch; r[xh::H_MUG + arm] = L.st.mug;
+    if (arm == 0) {
+        for (int i = 0; i < 3; i++) { r[xh::H_BP + i] = L.st.bp[i]; r[xh::H_BV + i] = L.st.bv[i]; r[xh::H_BW + i] = L.st.bw[i]; r[xh::H_GOAL + i] = L.st.goal[i]; }
+        for (int i = 0; i < 4; i++) r[xh::H_BQ + i] = L.st.bq[i];
+        for (int i = 0; i < 8; i++) r[xh::H_LT + i] = L.st.lam_t[i];
+        r[xh::H_STEPS] = L.st.steps; r[xh::H_EPISODE] = L.st.episode;
+    }
+}
+template <typename T> struct HoJob {
+    int mode; xh::EnvCfg cfg; int64_t E; double *state; const double *act; const uint8_t *mask;
+    double *obs, *ag, *dg, *rew; uint8_t *done, *succ; PairShared *sh; int arm;
+};
+template <typename T> void *ho_thread(void *p) {
+    HoJob<T> &J = *(HoJob<T> *)p;
+    PairXchg x{J.sh, J.arm};
+    for (int64_t e = 0; e < J.E; e++) {
+        if (J.mode == 1 && J.mask && !J.mask[e]) continue;
+        xh::Lane<T> L; T lds[xk::LDS_FLOATS]; HostLds<T> hl{lds};
+        hload(J.state + e * xh::STATE_DIM, J.arm, L);
+        T r = 0; bool d = false, su = false;
+        if (J.mode == 0) {
+            T a[4]; for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
+            xh::lane_step<T>(L, J.arm, a, r, d, su, hl, x);
+        } else xh::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
+        T o8[8];
+        xh::arm_obs(L, J.arm, o8);
+        pthread_barrier_wait(&J.sh->bar);   // both lanes finished computing before anyone overwrites the row
+        hstore(L, J.arm, J.state + e * xh::STATE_DIM);
+        double *o = J.obs + e * xh::OBS_DIM;
+        for (int k = 0; k < 8; k++) o[13 + 8 * J.arm + k] = o8[k];
+        if (J.arm == 0) {
+            for (int k = 0; k < 3; k++) { o[k] = L.st.bp[k]; o[7 + k] = L.st.bv[k]; o[10 + k] = L.st.bw[k]; J.ag[e * 3 + k] = L.st.bp[k]; J.dg[e * 3 + k] = L.st.goal[k]; }
+            for (int k = 0; k < 4; k++) o[3 + k] = L.st.bq[k];
+            if (J.mode == 0) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
+        }
+        pthread_barrier_wait(&J.sh->bar);
+    }
+    return 0;
+}
+template <typename T> void ho_run(int mode, const xh::EnvCfg &cfg, int64_t E, double *state, const double *act, const uint8_t *mask,
+                                  double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    PairShared sh;
+    pthread_barrier_init(&sh.bar, 0, 2);
+    HoJob<T> j[2];
+    pthread_t th[2];
+    for (int a = 0; a < 2; a++) { j[a] = HoJob<T>{mode, cfg, E, state, act, mask, obs, ag, dg, rew, done, succ, &sh, a}; pthread_create(&th[a], 0, ho_thread<T>, &j[a]); }
+    for (int a = 0; a < 2; a++) pthread_join(th[a], 0);
+    pthread_barrier_destroy(&sh.bar);
+}
+}
+
 extern "C" {
+static xh::EnvCfg hcfg(uint64_t seed, int64_t off, double ssr, int gs) { xh::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.same_side_rate = (float)ssr; c.goal_shape = gs; return c; }
+void xh_ho_init(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state) {
+    auto c = hcfg(seed, off, ssr, gs);
+    for (int64_t e = 0; e < E; e++) for (int a = 1; a >= 0; a--) {
+        if (f32) { xh::Lane<float> L; xh::lane_init<float>(c, e, L); hstore(L, a, state + e * xh::STATE_DIM); }
+        else { xh::Lane<double> L; xh::lane_init<double>(c, e, L); hstore(L, a, state + e * xh::STATE_DIM); }
+    }
+}
+void xh_ho_step(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) ho_run<float>(0, c, E, state, act, 0, obs, ag, dg, rew, done, succ); else ho_run<double>(0, c, E, state, act, 0, obs, ag, dg, rew, done, succ);
+}
+void xh_ho_reset(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) ho_run<float>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0); else ho_run<double>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0);
+}
 static xr::EnvCfg rcfg(uint64_t seed, int64_t off, int rt) { xr::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.reward_type = rt; return c; }
 void xh_reach_init(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state) { auto c = rcfg(seed, off, rt); if (f32) reach_init<float>(c, E, state); else reach_init<double>(c, E, state); }
 void xh_reach_step(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {

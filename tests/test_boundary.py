@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_struct_layout_matches_header():
     from gym_xarm_amd import _native
-    assert C.sizeof(_native.XarmConfig) == 56 and C.sizeof(_native.XarmDims) == 24
+    assert C.sizeof(_native.XarmConfig) == 64 and C.sizeof(_native.XarmDims) == 24
     src = open(HDR).read()
     fields = re.findall(r"^\s+(?:u?int\d+_t|float)\s+(\w+);", src[src.index("typedef struct xarm_config"):src.index("} xarm_config;")], flags=re.M)
     assert fields == [f[0] for f in _native.XarmConfig._fields_]
@@ -52,11 +52,11 @@ def test_library_contains_gfx950_code_object(lib):
 def test_no_device_errors_are_reported_not_thrown(lib):
     from gym_xarm_amd import _native
     L = _native.load()
-    bad = _native.XarmConfig(0, 0, 0, 0, 1, 0, 0, 0.0, 0.0, 1, 0)  # num_envs = 0
+    bad = _native.XarmConfig(0, 0, 0, 0, 1, 0, 0, 0.0, 0.0, 1, 0, 0.0, 0)  # num_envs = 0
     h = C.c_void_p(0)
     assert L.xarm_create(C.byref(bad), C.byref(h)) == -1 and not h.value
     assert b"num_envs" in L.xarm_last_error(None)
-    bad = _native.XarmConfig(4, 0, 0, 0, 2, 0, 0, 0.0, 0.0, 1, 0)  # num_obj = 2 unsupported
+    bad = _native.XarmConfig(4, 0, 0, 0, 2, 0, 0, 0.0, 0.0, 1, 0, 0.0, 0)  # num_obj = 2 unsupported
     assert L.xarm_create(C.byref(bad), C.byref(h)) == -1
     assert L.xarm_destroy(None) == 0 and L.xarm_step(None, *([None] * 9)) == -1
 

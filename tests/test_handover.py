@@ -1,0 +1,172 @@
+"""XarmHandover-v0 / XarmPDHandover-v0 (reference xarm_handover.py, num_obj = 1, use_stand False): oracle pinned by
+the reference's own NumPy code, the lane-pair kernel core (host build: two threads per env exchanging through a
+barrier, i.e. the same hand-over points as the DPP exchange on the GPU) against the oracle, and the HIP path
+through the C ABI.  Float tolerance as for PickAndPlace (oracle/parity.py: atol 5e-4 + rtol 2e-4 + 300 x
+oracle sensitivity, discontinuous transitions exempt)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONT = np.r_[0:36, 38:51]   # q, qd of both arms, object pose and velocity
+
+
+@pytest.fixture(scope="module")
+def gref():
+    return np.load(os.path.join(GOLDEN, "handover_reward_reference.npz"))
+
+
+@pytest.fixture(scope="module")
+def groll():
+    return np.load(os.path.join(GOLDEN, "handover_oracle_rollout.npz"))
+
+
+def test_reward_success_done_match_reference_golden(oracle, gref):
+    env = oracle.OracleHandover(1)
+    out = env.compute_reward(gref["achieved_goal"], gref["goal"])
+    assert np.array_equal(out, gref["reward_batch"])                 # -1 / -0 exactly (:177-183)
+    assert np.array_equal(out[:64], gref["reward_single"])
+    assert np.array_equal((out == 0).astype(float), gref["is_success"])
+    for k, steps in enumerate((1, 99, 100)):
+        done = (out == 0) | (steps == 100)
+        assert np.array_equal(done.astype(np.uint8), gref["done"][:, k])
+
+
+def test_oracle_handover_behaviour(oracle, groll):
+    """the reference's scripted ezpolicy (:404-446) really hands the stick over in the restated physics"""
+    S = groll["states"]
+    both = (S[:, :, 70:72].sum(axis=2) == 2).any(axis=0)
+    assert both.sum() >= 5                                            # both grippers hold the stick at some step
+    crossed = (S[30][:, 38] * S[0][:, 38] < 0) & (S[30][:, 40] > 0.03)
+    assert crossed.sum() >= 2                                         # ... and it ends on the other arm's side, lifted
+    js = oracle.load_model_json()["handover"]
+    env = oracle.OracleHandover(256, seed=4, same_side_rate=1.0, goal_shape="ground")
+    env.reset()
+    s = env.state
+    assert (np.sign(s[:, 51]) == np.sign(s[:, 38])).all() and (s[:, 53] == js["height_offset"]).all()    # same side, ground
+    assert (np.abs(s[:, 38]) >= js["obj_low"][0] - 0.02).all() and (np.abs(s[:, 38]) <= js["obj_high"][0] + 0.02).all()
+    env = oracle.OracleHandover(256, seed=4, same_side_rate=0.0, goal_shape="any")
+    env.reset()
+    assert (np.sign(env.state[:, 51]) == -np.sign(env.state[:, 38])).all() and (env.state[:, 53] > 0.025).any()
+    big, lo, hi = oracle.OracleHandover(8, seed=2), oracle.OracleHandover(4, seed=2), oracle.OracleHandover(4, seed=2, env_id_offset=4)
+    assert np.array_equal(big.state[:4], lo.state) and np.array_equal(big.state[4:], hi.state)
+
+
+def test_object_clamp_and_time_limit(oracle):
+    env = oracle.OracleHandover(4, seed=3)
+    env.reset()
+    st = env.get_state()
+    st[:, 38] = [0.5, -0.5, 0.1, -0.1]          # outside / inside the +-0.28 play field (:288-293)
+    st[:, 39] = [0.3, -0.3, 0.0, 0.0]
+    st[:, 41:45] = [0.3, 0.4, 0.2, 0.8426]       # arbitrary orientation -> only its pitch survives (:294-296)
+    st[:, 45:51] = 1.0
+    st[:, 74] = [99, 0, 99, 0]
+    env.set_state(st)
+    obs, ag, dg, rew, done, succ = env.step(np.zeros((4, 8)))
+    assert done[0] and done[2] and not done[1] and not done[3]          # TimeLimit(100)
+    assert (np.abs(ag[:, 0]) <= 0.28 + 0.02).all() and (np.abs(ag[:, 1]) <= 0.2 + 0.02).all()
+    assert np.abs(env.state[:, 45:48]).max() < 3.0                      # the injected 1 m/s was zeroed before the 15 ticks (free fall only)
+
+
+def test_hostcore_lane_pair_f64_equals_oracle(hostcore, groll):
+    g = groll
+    st = hostcore.ho_init(24, f32=0, seed=2)
+    np.testing.assert_allclose(st, g["init_state"], atol=1e-15)
+    st, obs, ag, dg = hostcore.ho_reset(st[:6], f32=0, seed=2)
+    np.testing.assert_allclose(st, g["states"][0][:6], atol=1e-9)
+    np.testing.assert_allclose(obs, g["reset_obs"][:6], atol=1e-9)
+    n_ok, n_all = 0, 0
+    sub = slice(0, 10)    # the two-thread lane emulation is slow: 10 envs, every third step (incl. the two-arm contact phase)
+    for t in range(0, g["actions"].shape[0], 3):
+        st, obs, ag, dg, rew, done, succ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=0, seed=2)
+        ok = g["sens"][t][sub] < 1e-2
+        err = np.abs(st - g["states"][t + 1][sub]).max(axis=1)
+        assert (err[ok] <= 1e-8 + 1e-3 * g["sens"][t][sub][ok]).all(), (t, err[ok].max())
+        np.testing.assert_allclose(obs[ok], g["obs"][t][sub][ok], atol=1e-7)
+        assert np.array_equal(rew[ok], g["rew"][t][sub][ok]) and np.array_equal(done[ok], g["done"][t][sub][ok])
+        n_ok += ok.sum()
+        n_all += ok.size
+    assert n_ok > 0.8 * n_all
+
+
+def test_hostcore_lane_pair_f32_within_tolerance(hostcore, groll, parity):
+    g = groll
+    sub = slice(0, 10)
+    for t in range(1, g["actions"].shape[0], 6):
+        st, *_ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=1, seed=2)
+        parity.compare(st[:, CONT], g["states"][t + 1][sub][:, CONT], g["sens"][t][sub], what="handover f32 t=%d" % t, frac_tight=0.5, max_exempt=0.4)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_handover_replays_golden_rollout(groll, parity):
+    import torch
+    import gym_xarm_amd as gx
+    g = groll
+    E = g["states"].shape[1]
+    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=2, auto_reset=False)
+    np.testing.assert_allclose(env.get_state().cpu().numpy(), g["init_state"], atol=1e-6)
+    obs = env.reset()
+    np.testing.assert_allclose(obs["observation"].cpu().numpy(), g["reset_obs"], atol=3e-3)
+    np.testing.assert_allclose(obs["desired_goal"].cpu().numpy(), g["states"][0][:, 51:54], atol=1e-6)
+    seen_both = 0
+    for t in range(g["actions"].shape[0]):
+        env.set_state(g["states"][t])
+        obs, rew, done, info = env.step(torch.tensor(g["actions"][t], dtype=torch.float32))
+        st = env.get_state().cpu().numpy().astype(np.float64)
+        sens = g["sens"][t]
+        parity.compare(st[:, CONT], g["states"][t + 1][:, CONT], sens, what="handover gpu t=%d" % t, frac_tight=0.6, max_exempt=0.3)
+        ok = sens < 1e-3
+        np.testing.assert_allclose(obs["observation"].cpu().numpy()[ok], g["obs"][t][ok], atol=3e-3)
+        assert np.array_equal(rew.cpu().numpy()[ok], g["rew"][t][ok].astype(np.float32))
+        assert np.array_equal(done.cpu().numpy()[ok], g["done"][t][ok])
+        assert np.array_equal(st[ok][:, 70:72], g["states"][t + 1][ok][:, 70:72])      # per-arm grasp flags
+        seen_both += (st[ok][:, 70:72].sum(axis=1) == 2).sum()
+    assert seen_both > 10                                   # the two-arm contact phase was really exercised
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_handover_16384_properties_and_registry(gref):
+    """BASELINE config 5 shard size (131 072 envs over 8 GPUs = 16 384 per GPU): invariants, determinism, shard
+    invariance, auto-reset, batched compute_reward, and the reference's test.py rollout pattern"""
+    import torch
+    import gym_xarm_amd as gx
+    E = 16384
+    acts = [torch.rand(E, 8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(k)) * 2 - 1 for k in range(3)]
+
+    def run(n, off):
+        env = gx.make("XarmPDHandover-v0", num_envs=n, seed=6, env_id_offset=off)
+        env.reset()
+        for k in range(3):
+            obs, rew, done, info = env.step(acts[k][off:off + n])
+        out = env.get_state().clone(), obs["observation"].clone(), rew.clone()
+        env.close()
+        return out
+    full, again, half = run(E, 0), run(E, 0), run(E // 2, E // 2)
+    for x, y, z in zip(full, again, half):
+        assert torch.equal(x, y) and torch.equal(x[E // 2:], z)
+    st = full[0]
+    assert torch.isfinite(st).all() and ((st[:, 41:45].norm(dim=1) - 1).abs() < 1e-5).all()
+    assert ((full[2] == 0) | (full[2] == -1)).all()
+    env = gx.make("XarmHandover-v0", num_envs=256, seed=1)
+    env.reset()
+    s = env.get_state()
+    s[:64, 74] = 99
+    env.set_state(s)
+    obs, rew, done, info = env.step(torch.zeros(256, 8))
+    assert done[:64].all() and (env.get_state()[:64, 74] == 0).all() and (env.get_state()[:64, 75] == 2).all()
+    out = env.compute_reward(torch.tensor(gref["achieved_goal"], dtype=torch.float32), torch.tensor(gref["goal"], dtype=torch.float32))
+    edge = np.abs(np.linalg.norm(gref["achieved_goal"] - gref["goal"], axis=1) - 0.05) < 1e-6
+    assert np.array_equal(out.cpu().numpy()[~edge], gref["reward_batch"][~edge].astype(np.float32))
+    env.close()
+    one = gx.make("XarmHandover-v0", config={"GUI": False, "num_obj": 1, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False})
+    ob = one.reset()
+    for i in range(12):
+        assert one.observation_space.contains(ob)
+        a = one.action_space.sample()
+        assert one.action_space.contains(a) and a.shape == (8,)
+        ob, r, d, info = one.step(a)
+        assert ob["observation"].shape == (29,) and r in (0.0, -1.0)
+    one.close()

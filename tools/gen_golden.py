@@ -149,6 +149,36 @@ def reach():
     print("wrote reach_reward_reference.npz")
 
 
+def handover():
+    """XarmHandover.compute_reward sparse (:164-183, incl. the batch form and N = 2), _is_success (:395-402) and the
+    done expression of step (:138) from the reference's own code."""
+    stub_modules()
+    sys.modules["pybullet_utils"] = sys.modules["pybullet"]
+    sys.modules["pybullet_utils.bullet_client"] = sys.modules["pybullet"]
+    sys.modules["pkgutil"] = __import__("pkgutil")
+    spec = importlib.util.spec_from_file_location("ref_ho", "/root/reference/gym_xarm/envs/xarm_handover.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cls = mod.XarmHandover
+    rng = np.random.default_rng(777)
+    n = 512
+    g = rng.uniform([-0.28, -0.18, 0.025], [0.28, 0.18, 0.2], size=(n, 3))
+    direction = rng.normal(size=(n, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    radius = np.concatenate([rng.uniform(0, 0.4, n // 2), 0.05 + rng.uniform(-2e-3, 2e-3, n // 4), rng.uniform(0, 0.05, n - n // 2 - n // 4)])
+    ag = g + direction * radius[:, None]
+    self = SimpleNamespace(reward_type="sparse", distance_threshold=0.05, config={"num_obj": 1})
+    out = {"achieved_goal": ag, "goal": g}
+    out["reward_batch"] = np.asarray(cls.compute_reward(self, ag, g, {}))
+    out["reward_single"] = np.array([cls.compute_reward(self, ag[i], g[i], {}) for i in range(64)])
+    out["is_success"] = np.array([cls._is_success(self, ag[i], g[i]) for i in range(n)])
+    steps = np.array([1, 99, 100])
+    out["done"] = np.array([[(s == 100) or bool(out["is_success"][i]) for s in steps] for i in range(n)], dtype=np.uint8)  # :138 with TimeLimit(100)
+    np.savez(os.path.join(OUT, "handover_reward_reference.npz"), **out)
+    print("wrote handover_reward_reference.npz")
+
+
 if __name__ == "__main__":
     main()
     reach()
+    handover()

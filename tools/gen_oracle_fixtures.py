@@ -107,6 +107,64 @@ def reach():
     print("wrote", path, "max sens %.2e" % np.max(sens_l))
 
 
+def _ezpolicy(o):
+    """the control law of the reference's scripted policy (xarm_handover.py:404-446), restated for fixtures"""
+    obj, g1, q1, g2, q2 = o[0:3], o[13:16], o[19], o[21:24], o[27]
+    ig1 = q1 < 0.25 and np.linalg.norm(obj - g1) < 0.05
+    ig2 = q2 < 0.25 and np.linalg.norm(obj - g2) < 0.05
+    d1 = obj - g1 + [-0.07, 0, 0]
+    d2 = obj - g2 + [0.07, 0, 0]
+    a = [0.0] * 8
+    a[3] = -0.5 if np.linalg.norm(obj - g1) < 0.1 else 0.5
+    a[7] = -0.5 if np.linalg.norm(obj - g2) < 0.1 else 0.5
+    if not ig1:
+        a[0:3] = list(d1 / np.linalg.norm(d1))
+    elif not ig2:
+        a[0:3] = [0.5, 0, 0.5]
+        a[4:7] = list(d2 / np.linalg.norm(d2))
+    else:
+        a[4] = -0.5
+    return a
+
+
+def handover():
+    """XarmHandover-v0: 24 envs under the reference's scripted handover policy for 30 steps + 8 random steps, with
+    sensitivities of the continuous state (q, qd of both arms, object pose / velocity)."""
+    E = 24
+    ora = O.OracleHandover(E, seed=2)
+    init = ora.get_state()
+    obs = ora.reset()[0]
+    reset_obs = obs.copy()
+    rng = np.random.default_rng(8)
+    states, acts, obs_l, rew_l, done_l, succ_l, sens_l = [ora.get_state()], [], [], [], [], [], []
+    cont = np.r_[0:36, 38:51]
+    for t in range(38):
+        a = np.array([_ezpolicy(obs[e]) for e in range(E)]) if t < 30 else rng.uniform(-1, 1, (E, 8))
+        s0 = states[-1]
+        ora.set_state(s0)
+        o = ora.step(a)
+        nxt = ora.get_state()
+        sens = np.zeros(E)
+        for k in range(2):
+            sp = s0.copy()
+            sp[:, cont] += np.random.default_rng(1000 * t + k).uniform(-1e-6, 1e-6, size=(E, cont.size))
+            qn = sp[:, 41:45]
+            sp[:, 41:45] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+            ora.set_state(sp)
+            ora.step(a)
+            sens = np.maximum(sens, np.abs(ora.get_state()[:, cont] - nxt[:, cont]).max(1))
+        ora.set_state(nxt)
+        obs = o[0]
+        states.append(nxt); acts.append(a); obs_l.append(o[0]); rew_l.append(o[3]); done_l.append(o[4]); succ_l.append(o[5]); sens_l.append(sens)
+    path = os.path.join(ROOT, "tests", "golden", "handover_oracle_rollout.npz")
+    np.savez_compressed(path, init_state=init, reset_obs=reset_obs, actions=np.stack(acts), states=np.stack(states), obs=np.stack(obs_l),
+                        rew=np.stack(rew_l), done=np.stack(done_l), succ=np.stack(succ_l), sens=np.stack(sens_l))
+    st = states[30]
+    print("wrote", path, "both arms touching at some step:", int((np.stack(states)[:, :, 70:72].sum(2) == 2).any(0).sum()),
+          "handed over:", int(((st[:, 38] * states[0][:, 38] < 0) | (st[:, 40] > 0.08)).sum()), "of", E, "max sens %.2e" % np.max(sens_l))
+
+
 if __name__ == "__main__":
     main()
     reach()
+    handover()

@@ -77,11 +77,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hooks for a 1-GPU box: XARM_BENCH_DEVICE pins every rank to one device, XARM_BENCH_BACKEND=gloo
+    # replaces RCCL (two ranks cannot share a device under RCCL); the driver's real runs use neither
+    dev_index = int(os.environ.get("XARM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("XARM_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     E = args.envs_per_gpu
     env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=0, env_id_offset=rank * E, device=dev,

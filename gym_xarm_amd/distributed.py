@@ -46,11 +46,16 @@ def gather_to_rank0(x, total_envs=None, group=None):
     return None
 
 
+def _coll_device(device):
+    """gloo reduces host tensors, RCCL device tensors"""
+    return None if dist.get_backend() == "gloo" else device
+
+
 def max_over_ranks(value, device=None, group=None):
     """MAX all-reduce of a python float (bench timing)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -58,6 +63,6 @@ def max_over_ranks(value, device=None, group=None):
 def sum_over_ranks(value, device=None, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())

@@ -201,3 +201,15 @@ def test_gpu_reach_4096_episode_and_registry(gref):
         if d:
             ob = one.reset()
     one.close()
+
+
+@pytest.mark.gpu
+def test_gpu_a2c_learns_reach():
+    """the reference's consumer of the env boundary (benchmark/train.py: VecNormalize + A2C) on the batched env:
+    a few hundred on-device A2C updates must improve the dense Reach reward markedly"""
+    from gym_xarm_amd.train import train
+    model, venv, hist = train("XarmReach-v0", num_envs=2048, updates=300, config={"reward_type": "dense", "GUI": False},
+                              log_every=50, quiet=True)
+    first, last = hist[0]["mean_raw_reward"], hist[-1]["mean_raw_reward"]
+    assert last > first + 0.03, (first, last, hist)          # mean -distance to the goal shrinks by > 3 cm
+    assert hist[-1]["env_steps_per_sec"] > 2e5

@@ -133,7 +133,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world,
+            "metric": "env steps/sec (whole node), XarmPDPickAndPlace-v0", "value": value, "unit": "env steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",

@@ -170,3 +170,15 @@ def test_gpu_handover_16384_properties_and_registry(gref):
         ob, r, d, info = one.step(a)
         assert ob["observation"].shape == (29,) and r in (0.0, -1.0)
     one.close()
+
+
+@pytest.mark.gpu
+def test_gpu_scripted_handover_rate():
+    """behavioural regression: the reference's ezpolicy, run on the GPU env, hands a good share of the sticks that
+    start on arm 1's side over to arm 2 (lifted, held by arm 2 alone)"""
+    import gym_xarm_amd as gx
+    from gym_xarm_amd.policies import handover_rate
+    env = gx.make("XarmPDHandover-v0", num_envs=2048, seed=11, auto_reset=False)
+    rate = handover_rate(env, steps=40)
+    env.close()
+    assert rate > 0.06, rate     # ~0.12-0.13 measured; the reference controller is crude (no alignment of the grasp)

@@ -287,3 +287,41 @@ def test_scripted_pick_and_lift_rate(gx, tmp_path):
     obs2 = env.step(torch.zeros(E, 4))[0]["observation"]
     assert torch.equal(obs1, obs2)                       # restored state reproduces the step bitwise
     env.close()
+
+
+def test_rollout_statistics_match_oracle(gx, oracle):
+    """Past contact onset trajectories diverge (chaotic contact dynamics), so long-horizon parity is asserted on
+    distributions (SURVEY.md 7 'Hard parts'): 2048 envs x 30 random steps from the same seeds, HIP vs oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    E, T, W = 2048, 30, 16
+    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=123, auto_reset=False)
+    env.reset()
+    acts = [torch.rand(E, 4, generator=torch.Generator().manual_seed(100 + t)) * 2 - 1 for t in range(T)]
+    for t in range(T):
+        obs, rew, done, info = env.step(acts[t])
+    dev = _np(env.get_state()).astype(np.float64)
+    env.close()
+    shards = [oracle.OraclePnP(E // W, seed=123, env_id_offset=k * (E // W)) for k in range(W)]
+    a_np = [a.numpy().astype(np.float64) for a in acts]
+
+    def run(k):
+        s = shards[k]
+        s.reset()
+        for t in range(T):
+            s.step(a_np[t][k * (E // W):(k + 1) * (E // W)])
+        return s.state
+    with ThreadPoolExecutor(W) as ex:
+        ora = np.concatenate(list(ex.map(run, range(W))))
+
+    def stats(s):
+        on_table = (s[:, 20] > 0.02) & (s[:, 20] < 0.1)
+        return np.array([on_table.mean(), (s[:, 20] < -0.05).mean(), (s[:, 20] > 0.1).mean(), s[:, 50].mean(),
+                         np.median(s[:, 18]), np.median(np.abs(s[:, 19])), s[:, 7].mean(), np.abs(s[:, 9:16]).mean()])
+    sd, so = stats(dev), stats(ora)
+    # fractions agree within 3 sigma of a binomial with n = 2048 (<= 0.035) plus model noise; medians within 1 cm
+    tol = np.array([0.04, 0.04, 0.04, 0.04, 0.01, 0.01, 0.002, 0.05])
+    assert (np.abs(sd - so) <= tol).all(), (sd, so)
+    # the arm itself is well conditioned: joint angles of envs whose object never came near the gripper agree closely
+    calm = (np.abs(ora[:, 20] - 0.04) < 1e-3) & (np.abs(dev[:, 20] - 0.04) < 1e-3) & (ora[:, 50] == 0)
+    assert calm.mean() > 0.2
+    assert np.median(np.abs(dev[calm, :7] - ora[calm, :7]).max(axis=1)) < 2e-3

@@ -651,7 +651,15 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     T g_lam = (T)0;
 
     // ---------------- (F) finger pad spheres against the object
+    static_assert(xm::NPAD == 2, "the finger block below fuses exactly two pad points per finger");
     PadPoint<T> pp[NP];
+    // K21[fk]: change of the relative velocity at the finger's second pad point per unit impulse at its first one
+    // (3x3, row-major); lets both points of a finger be swept before ONE operational-space update
+    T K21[2][9];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) K21[k][e] = (T)0;
     bool pad_any = false;
     bool touch_f[2] = {false, false};
     const T pad_denom = dt * (T)xm::FINGER_CONTACT_STIFFNESS + (T)(xm::FINGER_CONTACT_DAMPING + xm::OBJECT_CONTACT_DAMPING);
@@ -758,6 +766,35 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
                 for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
                 dq[r] += s;
+            }
+            // coupling of the two pad points of each finger: relative velocity at point 2 per unit impulse at point 1
+#pragma unroll
+            for (int fk = 0; fk < 2; fk++) {
+                const PadPoint<T> &P1 = pp[2 * fk], &P2 = pp[2 * fk + 1];
+                if (!XARM_ANY(P1.invd[0] != (T)0 && P2.invd[0] != (T)0)) continue;
+                const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
+                const V3<T> r1 = P1.p - cb, r2 = P2.p - cb;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const V3<T> ej = mk<T>(e == 0 ? (T)1 : (T)0, e == 1 ? (T)1 : (T)0, e == 2 ? (T)1 : (T)0);
+                    const V3<T> mo = cross(P1.p, ej);
+                    const T W[6] = {mo.x, mo.y, mo.z, ej.x, ej.y, ej.z};
+                    const T wf = comp(af, e);
+                    T Y[6];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
+#pragma unroll
+                        for (int b = 0; b < 6; b++) s += lds[LDS_AHH + symi(a, b)] * W[b];
+                        Y[a] = s;
+                    }
+                    T yf = Minv[tri(7 + fk, 7 + fk)] * wf;
+#pragma unroll
+                    for (int b = 0; b < 6; b++) yf += lds[LDS_T + (7 + fk) * 6 + b] * W[b];
+                    const V3<T> va = mk<T>(Y[3], Y[4], Y[5]) + cross(mk<T>(Y[0], Y[1], Y[2]), P2.p) + af * yf;
+                    const V3<T> vbj = ej * imb - cross(r2, symmul(Iinv, cross(r1, ej)));
+                    K21[fk][0 * 3 + e] = va.x + vbj.x; K21[fk][1 * 3 + e] = va.y + vbj.y; K21[fk][2 * 3 + e] = va.z + vbj.z;
+                }
             }
         }
         if (Scene::NARMS == 2) {
@@ -871,38 +908,53 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
             for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
-            for (int idx = 0; idx < NP; idx++) {
-                PadPoint<T> &P = pp[idx];
-                if (!XARM_ANY(P.invd[0] != (T)0 && mine)) continue;
-                const T e0 = mine ? P.invd[0] : (T)0, e1 = mine ? P.invd[1] : (T)0, e2 = mine ? P.invd[2] : (T)0;
-                const int fk = idx / xm::NPAD;
+            for (int fk = 0; fk < 2; fk++) {
+                PadPoint<T> &P1 = pp[2 * fk], &P2 = pp[2 * fk + 1];
+                if (!XARM_ANY((P1.invd[0] != (T)0 || P2.invd[0] != (T)0) && mine)) continue;
                 const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
-                const V3<T> r = P.p - cb;
-                const V3<T> t2 = cross(P.n, P.t1);
-                V3<T> u = mk<T>(y[3], y[4], y[5]) + cross(mk<T>(y[0], y[1], y[2]), P.p) + af * yf[fk] - vb - cross(wb, r);
-                T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
-                T nl = P.lam[0] + dl;
-                nl = nl < (T)0 ? (T)0 : nl;
-                dl = nl - P.lam[0];
-                P.lam[0] = nl;
-                V3<T> fi = P.n * dl;
-                u = u + P.Kn * dl;
-                const T lim = mu_p * P.lam[0];
-                dl = -dot(P.t1, u) * e1;
-                nl = clampT(P.lam[1] + dl, -lim, lim);
-                dl = nl - P.lam[1];
-                P.lam[1] = nl;
-                fi = fi + P.t1 * dl;
-                u = u + P.Kt1 * dl;
-                dl = -dot(t2, u) * e2;
-                nl = clampT(P.lam[2] + dl, -lim, lim);
-                dl = nl - P.lam[2];
-                P.lam[2] = nl;
-                fi = fi + t2 * dl;
-                // apply the block impulse: +fi on finger fk at p, -fi on the object
-                const V3<T> mo = cross(P.p, fi);
-                const T W[6] = {mo.x, mo.y, mo.z, fi.x, fi.y, fi.z};
-                const T wf = dot(af, fi);
+                const V3<T> yw = mk<T>(y[0], y[1], y[2]);
+                const V3<T> base = mk<T>(y[3], y[4], y[5]) + af * yf[fk] - vb;
+                V3<T> fsum = mk<T>(0, 0, 0), msum = mk<T>(0, 0, 0), bsum = mk<T>(0, 0, 0); // sum f, sum p x f, sum r x f
+                V3<T> f1 = mk<T>(0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    PadPoint<T> &P = j == 0 ? P1 : P2;
+                    const T e0 = mine ? P.invd[0] : (T)0, e1 = mine ? P.invd[1] : (T)0, e2 = mine ? P.invd[2] : (T)0;
+                    const V3<T> r = P.p - cb;
+                    const V3<T> t2 = cross(P.n, P.t1);
+                    V3<T> u = base + cross(yw, P.p) - cross(wb, r);
+                    if (j == 1) // effect of the impulse just applied at this finger's first point
+                        u = u + mk<T>(K21[fk][0] * f1.x + K21[fk][1] * f1.y + K21[fk][2] * f1.z,
+                                      K21[fk][3] * f1.x + K21[fk][4] * f1.y + K21[fk][5] * f1.z,
+                                      K21[fk][6] * f1.x + K21[fk][7] * f1.y + K21[fk][8] * f1.z);
+                    T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
+                    T nl = P.lam[0] + dl;
+                    nl = nl < (T)0 ? (T)0 : nl;
+                    dl = nl - P.lam[0];
+                    P.lam[0] = nl;
+                    V3<T> fi = P.n * dl;
+                    u = u + P.Kn * dl;
+                    const T lim = mu_p * P.lam[0];
+                    dl = -dot(P.t1, u) * e1;
+                    nl = clampT(P.lam[1] + dl, -lim, lim);
+                    dl = nl - P.lam[1];
+                    P.lam[1] = nl;
+                    fi = fi + P.t1 * dl;
+                    u = u + P.Kt1 * dl;
+                    dl = -dot(t2, u) * e2;
+                    nl = clampT(P.lam[2] + dl, -lim, lim);
+                    dl = nl - P.lam[2];
+                    P.lam[2] = nl;
+                    fi = fi + t2 * dl;
+                    if (j == 0) f1 = fi;
+                    fsum = fsum + fi;
+                    msum = msum + cross(P.p, fi);
+                    bsum = bsum + cross(r, fi);
+                }
+                // ONE operational-space update for the finger: +fsum on finger fk (moment msum about the world
+                // origin), -fsum on the object (moment bsum about its centre)
+                const T W[6] = {msum.x, msum.y, msum.z, fsum.x, fsum.y, fsum.z};
+                const T wf = dot(af, fsum);
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
                     T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
@@ -920,8 +972,8 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
                 for (int b = 0; b < 6; b++) wtot[b] += W[b];
                 wtot[6 + fk] += wf;
-                vb = vb - fi * imb;
-                wb = wb - symmul(Iinv, cross(r, fi));
+                vb = vb - fsum * imb;
+                wb = wb - symmul(Iinv, bsum);
             }
 #pragma unroll
             for (int r = 0; r < 9; r++) {

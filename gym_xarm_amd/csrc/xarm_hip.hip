@@ -44,6 +44,14 @@ struct KParams {
     xh::EnvCfg hcfg;
 };
 
+// Output addresses are per-lane 64-bit values that LLVM would otherwise compute in the prologue and keep (spill)
+// across the whole simulation; re-deriving the env index through an opaque move pins them to the epilogue.
+__device__ __forceinline__ int64_t late_index(int64_t e) {
+    int lo = (int)e, hi = (int)(e >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi) : : "memory");
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
 __device__ __forceinline__ void load_state(const KParams &P, int64_t e, xk::EnvState<float> &s) {
     const float *S = P.state + e;
     const int64_t n = P.stride;
@@ -101,17 +109,18 @@ __global__ __launch_bounds__(WG) void k_step(KParams P, const float *__restrict_
                                              int *__restrict__ done_list, int *__restrict__ done_count,
                                              int *__restrict__ stale_count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
-    const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
-    if (e == 0 && stale_count) *stale_count = 0; // counter of the step before last, consumed by its k_reset
-    if (e >= P.num_envs) return;
+    const int64_t e_in = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e_in == 0 && stale_count) *stale_count = 0; // counter of the step before last, consumed by its k_reset
+    if (e_in >= P.num_envs) return;
     DevLds lds{smem + threadIdx.x};
     xk::EnvState<float> s;
-    load_state(P, e, s);
-    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e];
+    load_state(P, e_in, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float obs[xk::OBS_DIM], reward;
     bool done, success;
     xk::env_step<float, DevLds>(P.cfg, s, act, obs, reward, done, success, lds);
+    const int64_t e = late_index(e_in);
     store_state(P, e, s);
     write_obs(obs, s, e, obs_out, ag_out, dg_out);
     rew_out[e] = reward;
@@ -136,11 +145,12 @@ __global__ __launch_bounds__(WG) void k_reset(KParams P, const int *__restrict__
     const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (i >= n) return;
-    const int64_t e = list ? (int64_t)list[i] : i;
+    const int64_t e_in = list ? (int64_t)list[i] : i;
     DevLds lds{smem + threadIdx.x};
     xk::EnvState<float> s;
-    load_state(P, e, s);
-    xk::env_reset<float, DevLds>(P.cfg, e, s, lds);
+    load_state(P, e_in, s);
+    xk::env_reset<float, DevLds>(P.cfg, e_in, s, lds);
+    const int64_t e = late_index(e_in);
     store_state(P, e, s);
     if (obs_out) {
         float obs[xk::OBS_DIM];
@@ -358,18 +368,19 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
                                                 int *__restrict__ stale_count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
-    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e = t >> 1;
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
     const int arm = (int)(t & 1);
     if (t == 0 && stale_count) *stale_count = 0;
-    if (e >= P.num_envs) return;
+    if (e_in >= P.num_envs) return;
     DevLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
-    ho_load(P, e, arm, L);
-    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e * 2 + arm];
+    ho_load(P, e_in, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
     xh::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg());
+    const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
     if (done && P.auto_reset && term_obs) ho_write_obs(L, e, arm, term_obs, ag_out, dg_out);
@@ -390,11 +401,12 @@ __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restric
     const int arm = (int)(t & 1);
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (i >= n) return;
-    const int64_t e = list ? (int64_t)list[i] : i;
+    const int64_t e_in = list ? (int64_t)list[i] : i;
     DevLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
-    ho_load(P, e, arm, L);
-    xh::lane_reset<float, DevLds, DppXchg>(P.hcfg, e, L, arm, lds, DppXchg());
+    ho_load(P, e_in, arm, L);
+    xh::lane_reset<float, DevLds, DppXchg>(P.hcfg, e_in, L, arm, lds, DppXchg());
+    const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     if (obs_out) ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
 }

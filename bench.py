@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 6.3 TB/s achievable)
-FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak, for the secondary (honest) bound
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CU x 4 SIMD x 16 lanes x 2 pk x 2 fma x 2.4 GHz), the bound that binds
 ALGO_BYTES_PER_ENV_STEP = 452  # SURVEY.md 8(d), PnP N=1: state in+out, action in, obs/goals/reward/flags out
 
 
@@ -132,6 +132,18 @@ def main():
                 traffic = json.load(open(pmc)).get("k_step_hbm_bytes_per_launch_%d" % E)
             except Exception:
                 traffic = None
+        # secondary ceiling (the one that actually binds): fp32 vector issue.  Wave-instruction count per launch
+        # from the committed SQ_INSTS_VALU PMC pass, 64 lanes x 2 flop upper bound per instruction.
+        valu = None
+        if traffic is not None:
+            try:
+                n_valu = json.load(open(pmc)).get("k_step_valu_wave_insts_per_launch_%d" % E)
+                if n_valu:
+                    tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
+                    valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction)",
+                            "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu}
+            except Exception:
+                valu = None
         out = {
             "metric": "env steps/sec (whole node), XarmPDPickAndPlace-v0", "value": value, "unit": "env steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -146,6 +158,8 @@ def main():
                          "note": "fused step: HBM is touched once per env step, the kernel is fp32-VALU/latency bound (DESIGN.md)"},
             "kernel_only_env_steps_per_sec_per_gpu": E / (kstep_ms * 1e-3),
         }
+        if valu is not None:
+            out["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

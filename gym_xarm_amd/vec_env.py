@@ -31,6 +31,7 @@ class XarmPickAndPlaceVecEnv:
 
     metadata = {"render.modes": ["rgb_array"], "video.frames_per_second": 30}
     ENV_KIND = _native.ENV_PICK_AND_PLACE
+    AG_SLICE = slice(8, 11)   # achieved_goal = object position inside `observation` (xarm_pick_and_place.py:228-246)
 
     def _check_config(self, config):
         cfg = dict(CONFIG_DEFAULTS)
@@ -135,6 +136,19 @@ class XarmPickAndPlaceVecEnv:
 
     def _extra_info(self, info):
         pass
+
+    @property
+    def max_episode_steps(self):
+        return self._max_episode_steps
+
+    @property
+    def action_dim(self):
+        return self.act_dim
+
+    def achieved_goal_of(self, observation):
+        """achieved_goal carried inside an `observation` row - needed for info['terminal_observation'], which
+        holds the last observation of a finished episode but not its goal dict"""
+        return observation[..., self.AG_SLICE]
 
     def episode_steps(self):
         """int32 [E]: steps taken in the current episode of every env"""
@@ -249,6 +263,7 @@ class XarmReachVecEnv(XarmPickAndPlaceVecEnv):
     dense_diff (:107-116), info['future_length'] (:90)."""
 
     ENV_KIND = _native.ENV_REACH
+    AG_SLICE = slice(0, 3)    # achieved_goal = gripper position (xarm_reach.py:154-161)
 
     def _check_config(self, config):
         cfg = dict(REACH_CONFIG_DEFAULTS)
@@ -281,6 +296,7 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
     -[d > 0.05] (:177-183), done = success or 100 steps (:138 + registry).  num_obj = 1, use_stand = False."""
 
     ENV_KIND = _native.ENV_HANDOVER
+    AG_SLICE = slice(0, 3)    # achieved_goal = object position (xarm_handover.py:325-336)
 
     def _check_config(self, config):
         cfg = dict(HANDOVER_CONFIG_DEFAULTS)

@@ -79,6 +79,21 @@ class XoHoCfg(C.Structure):
 HO_STATE_DIM, HO_OBS_DIM, HO_ACT_DIM = 76, 29, 8
 
 
+class XoStCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("reward_type", _i), ("n_substeps", _i),
+                ("max_episode_steps", _i), ("reserved", _i),
+                ("time_step", _d), ("action_dt", _d), ("max_vel", _d), ("max_gripper_vel", _d),
+                ("pos_low", (_d * 3) * 2), ("pos_high", (_d * 3) * 2), ("goal_low", _d * 2), ("goal_high", _d * 2),
+                ("obj_low", _d * 2), ("obj_high", _d * 2), ("gripper_low", _d), ("gripper_high", _d), ("height_offset", _d),
+                ("joint_init_pos", _d * 9), ("base_pos", (_d * 3) * 2), ("base_yaw", _d * 2),
+                ("finger_motor_force", _d), ("distance_threshold", _d), ("cube_half", _d), ("cube_mass", _d)]
+
+
+ST_STATE_DIM, ST_OBS_DIM, ST_ACT_DIM, ST_GOAL_DIM = 136, 55, 8, 9
+# state offsets (oracle/xarm_oracle_stack.inc.c)
+ST_Q, ST_QD, ST_QT, ST_BP, ST_BQ, ST_BV, ST_BW, ST_GOAL, ST_LT, ST_LP, ST_STEPS, ST_EPISODE = 0, 18, 36, 54, 63, 75, 84, 93, 102, 126, 134, 135
+
+
 class XoPnpCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("init_grasp_rate", _d),
                 ("goal_ground_rate", _d), ("goal_shape", _i), ("reward_type", _i)]
@@ -165,6 +180,11 @@ def lib():
         L.xo_ho_reset.argtypes = [mp, hp, C.c_int64, dp, u8p, dp, dp, dp]
         L.xo_ho_step.argtypes = [mp, hp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
         L.xo_ho_compute_reward.argtypes = [hp, C.c_int64, dp, dp, dp]
+        sp = C.POINTER(XoStCfg)
+        L.xo_st_init.argtypes = [mp, sp, C.c_int64, dp]
+        L.xo_st_reset.argtypes = [mp, sp, C.c_int64, dp, u8p, dp, dp, dp]
+        L.xo_st_step.argtypes = [mp, sp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
+        L.xo_st_compute_reward.argtypes = [sp, _i, C.c_int64, dp, dp, dp]
         rp = C.POINTER(XoReachCfg)
         L.xo_reach_init.argtypes = [mp, rp, C.c_int64, dp]
         L.xo_reach_reset.argtypes = [mp, rp, C.c_int64, dp, u8p, dp, dp, dp]
@@ -348,6 +368,73 @@ class OracleHandover:
 
     def set_state(self, s):
         self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, HO_STATE_DIM)
+
+
+class OracleStackTower:
+    """Batched CPU XarmPDStackTower-v0 (xarm_stack_tower.py: two arms, three cubes), float64."""
+
+    def __init__(self, num_envs, seed=0, env_id_offset=0, reward_type="sparse"):
+        self.L = lib()
+        js = load_model_json()
+        self.m = build_model(js)
+        h = js["stack_tower"]
+        c = XoStCfg()
+        c.seed, c.env_id_offset = seed, env_id_offset
+        c.reward_type = 0 if reward_type == "sparse" else 1
+        for k in ("n_substeps", "max_episode_steps", "time_step", "action_dt", "max_vel", "max_gripper_vel", "gripper_low",
+                  "gripper_high", "height_offset", "finger_motor_force", "distance_threshold", "cube_half", "cube_mass"):
+            setattr(c, k, h[k])
+        for k in ("pos_low", "pos_high", "base_pos"):
+            for a in range(2):
+                for i in range(3):
+                    getattr(c, k)[a][i] = h[k][a][i]
+        for k, n in (("goal_low", 2), ("goal_high", 2), ("obj_low", 2), ("obj_high", 2), ("joint_init_pos", 9), ("base_yaw", 2)):
+            for i in range(n):
+                getattr(c, k)[i] = h[k][i]
+        self.cfg = c
+        self.E = int(num_envs)
+        self.state = np.zeros((self.E, ST_STATE_DIM))
+        self.L.xo_st_init(self.m, self.cfg, self.E, _p(self.state))
+
+    def _bufs(self):
+        return np.zeros((self.E, ST_OBS_DIM)), np.zeros((self.E, 9)), np.zeros((self.E, 9))
+
+    def reset(self, mask=None):
+        obs, ag, dg = self._bufs()
+        mk = None if mask is None else _u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xo_st_reset(self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
+        return obs, ag, dg
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.E, ST_ACT_DIM)
+        obs, ag, dg = self._bufs()
+        rew, done, succ = np.zeros(self.E), np.zeros(self.E, np.uint8), np.zeros(self.E, np.uint8)
+        self.L.xo_st_step(self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg), _p(rew), _u8(done), _u8(succ))
+        return obs, ag, dg, rew, done, succ
+
+    def compute_reward(self, ag, g, reward_type="sparse"):
+        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, 9)
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, 9)
+        out = np.zeros(ag.shape[0])
+        self.L.xo_st_compute_reward(self.cfg, 0 if reward_type == "sparse" else 1, ag.shape[0], _p(ag), _p(g), _p(out))
+        return out
+
+    def get_state(self):
+        return self.state.copy()
+
+    def set_state(self, s):
+        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, ST_STATE_DIM)
+
+
+def box_box(pA, RA, hA, pB, RB, hB, margin):
+    """-> (points [n,3], normal [3] from B to A, dist [n]) of the cube/cube manifold (xo_box_box)"""
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pA, RA, hA, pB, RB, hB)]
+    pts, nrm, dist = np.zeros((4, 3)), np.zeros(3), np.zeros(4)
+    L = lib()
+    L.xo_box_box.restype = C.c_int
+    L.xo_box_box.argtypes = [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 3
+    n = L.xo_box_box(*[x.ctypes.data for x in a], float(margin), pts.ctypes.data, nrm.ctypes.data, dist.ctypes.data)
+    return pts[:n].copy(), nrm, dist[:n].copy()
 
 
 def dense_reward(if_grasp, hand_com, ag, g, model=None):

@@ -1502,3 +1502,5 @@ int xo_ho_step(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state, 
     }
     return 0;
 }
+
+#include "xarm_oracle_stack.inc.c"

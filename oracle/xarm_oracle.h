@@ -148,6 +148,32 @@ int xo_ho_step(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state
                double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success);
 /* sparse reward of xarm_handover.py:177-183 for N = 1 over n rows */
 int xo_ho_compute_reward(const xo_ho_cfg *cfg, int64_t n, const double *ag, const double *g, double *out);
+/* ---- XarmPDStackTower-v0 (xarm_stack_tower.py), two xarm7_pd arms + three cubes ---- */
+#define XO_ST_STATE_DIM 136 /* q[2][9] qd[2][9] motor_target[2][9] cube_pos[3][3] cube_quat[3][4] cube_v[3][3]
+                               cube_w[3][3] goal[3][3] lam_table[3][8] lam_pad[2][4] num_steps episode */
+#define XO_ST_OBS_DIM 55
+#define XO_ST_ACT_DIM 8
+#define XO_ST_GOAL_DIM 9
+typedef struct {
+    uint64_t seed;
+    int64_t env_id_offset;
+    int32_t reward_type;        /* 0 sparse -(d > thr), else -d (:124-129) */
+    int32_t n_substeps, max_episode_steps, reserved;
+    double time_step, action_dt, max_vel, max_gripper_vel;
+    double pos_low[2][3], pos_high[2][3], goal_low[2], goal_high[2], obj_low[2], obj_high[2];
+    double gripper_low, gripper_high, height_offset, joint_init_pos[9];
+    double base_pos[2][3], base_yaw[2];
+    double finger_motor_force, distance_threshold, cube_half, cube_mass;
+} xo_st_cfg;
+int xo_st_init(const xo_model *m, const xo_st_cfg *cfg, int64_t E, double *state);
+int xo_st_reset(const xo_model *m, const xo_st_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,
+                double *ag, double *dg);
+int xo_st_step(const xo_model *m, const xo_st_cfg *cfg, int64_t E, double *state, const double *actions, double *obs,
+               double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success);
+int xo_st_compute_reward(const xo_st_cfg *cfg, int reward_type, int64_t n, const double *ag, const double *g, double *out);
+/* box/box manifold used by the cube/cube rows: <= 4 points, normal from B to A, signed distances */
+int xo_box_box(const double *pA, const double *RA, const double *hA, const double *pB, const double *RB,
+               const double *hB, double margin, double *pts /*[4][3]*/, double *nrm, double *dist);
 /* diagnostics used by tests */
 int xo_fk(const xo_model *m, const double *q, double *link_pos /*[n_links*3]*/,
           double *link_rot /*[n_links*9]*/);

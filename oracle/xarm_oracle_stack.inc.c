@@ -1,0 +1,586 @@
+/* XarmPDStackTower-v0 (BASELINE config 4) - CPU restatement, TEST INFRASTRUCTURE ONLY.
+ * Included at the end of xarm_oracle.c (it reuses that file's static tree / ABA / IK helpers).
+ *
+ * Follows /root/reference/gym_xarm/envs/xarm_stack_tower.py: two xarm7_pd arms at (-+0.6, 0, 0), the second yawed
+ * by pi (:37-40), three 0.05 m cubes of 0.1 kg (:59-65), one table (:57), step = clip action, per-arm Cartesian
+ * target + IK + POSITION_CONTROL motors (:142-162), one stepSimulation of 15 substeps (:104-105), obs 55 (:164-199),
+ * reward -(|ag - g| > 0.09) over the 9-vector (:124-129), reset = teleport the arms, respawn the cubes, one tick,
+ * sample the tower goal (:201-219).
+ *
+ * PARITY UNPINNED for the physics (PyBullet is absent): the contact model is this build's own statement
+ * of Bullet's pipeline and is recorded in gym_xarm_amd/model/xarm7_pd.json["stack_tower"]["_contact_model"]:
+ *   - cube corners against the table top, first 4 active corners per cube (as PickAndPlace);
+ *   - cube/cube: 15-axis separating-axis test; a face axis gives the incident face clipped against the reference
+ *     face (<= 4 points kept: the deepest, then the three closest to 90 degree steps around the centroid), an
+ *     edge/edge axis gives one point midway between the closest points of the two edges (the algorithm family of
+ *     Bullet's btBoxBoxDetector); speculative points up to solver_margin, no warm start;
+ *   - each pad sphere against its nearest cube only.
+ * The reward / success arithmetic IS pinned by tests/golden/stack_reward_reference.npz (reference NumPy code). */
+
+#define ST_NOBJ 3
+#define ST_NPAIR 3
+enum { K_Q = 0, K_QD = 18, K_QT = 36, K_BP = 54, K_BQ = 63, K_BV = 75, K_BW = 84, K_GOAL = 93, K_LT = 102, K_LP = 126,
+       K_STEPS = 134, K_EPISODE = 135 };
+
+typedef struct {
+    int arm;        /* articulated side (positive), -1 none */
+    int bp, bn;     /* cube on the positive / negative side, -1 none */
+    real Ja[XO_MAXD], Ba[XO_MAXD], Jp[6], Bp[6], Jn[6], Bn[6];
+    real vt, cfm, inv_d, lo, hi, lam, mu;
+    int normal_row;
+} srow_t;
+#define ST_MAXROWS 192
+typedef struct {
+    const xo_model *m;
+    const xo_st_cfg *c;
+    tree_t t[2];
+    real imass, iinertia;
+    srow_t rows[ST_MAXROWS];
+    int nrows;
+} ssolver_t;
+
+static srow_t *srow_new(ssolver_t *s) {
+    srow_t *r = &s->rows[s->nrows++];
+    memset(r, 0, sizeof *r);
+    r->arm = r->bp = r->bn = r->normal_row = -1;
+    return r;
+}
+static void srow_finish(ssolver_t *s, srow_t *r) {
+    real d = 0;
+    if (r->arm >= 0) {
+        aba_impulse_response(s->m, &s->t[r->arm], r->Ja, r->Ba);
+        for (int k = 0; k < 9; k++) d += r->Ja[k] * r->Ba[k];
+    }
+    if (r->bp >= 0)
+        for (int k = 0; k < 6; k++) { r->Bp[k] = r->Jp[k] * (k < 3 ? s->imass : s->iinertia); d += r->Jp[k] * r->Bp[k]; }
+    if (r->bn >= 0)
+        for (int k = 0; k < 6; k++) { r->Bn[k] = r->Jn[k] * (k < 3 ? s->imass : s->iinertia); d += r->Jn[k] * r->Bn[k]; }
+    r->inv_d = 1.0 / (d + r->cfm);
+}
+/* three rows of one contact point; n points from the negative body to the positive one.
+ * positive side: arm link (arm >= 0) or cube bp; negative side: cube bn or static (-1). */
+static int st_add_contact(ssolver_t *s, int arm, int link, int bp, int bn, const real *cp, const real *cn,
+                          const real *p, const real *n, real dist, real dt, real erp, real cfm, real mu, real lam0) {
+    real t1[3], t2[3];
+    plane_space(n, t1, t2);
+    const real *dirs[3] = {n, t1, t2};
+    int first = s->nrows;
+    for (int k = 0; k < 3; k++) {
+        srow_t *row = srow_new(s);
+        if (arm >= 0) {
+            row->arm = arm;
+            point_jacobian_row(s->m, &s->t[arm], link, p, dirs[k], row->Ja);
+        }
+        if (bp >= 0) {
+            real r[3], rxd[3];
+            v3_sub(r, p, cp);
+            v3_cross(rxd, r, dirs[k]);
+            row->bp = bp;
+            for (int c = 0; c < 3; c++) { row->Jp[c] = dirs[k][c]; row->Jp[c + 3] = rxd[c]; }
+        }
+        if (bn >= 0) {
+            real r[3], rxd[3];
+            v3_sub(r, p, cn);
+            v3_cross(rxd, r, dirs[k]);
+            row->bn = bn;
+            for (int c = 0; c < 3; c++) { row->Jn[c] = -dirs[k][c]; row->Jn[c + 3] = -rxd[c]; }
+        }
+        if (k == 0) {
+            row->vt = dist < 0 ? -erp * dist / dt : -dist / dt;
+            row->cfm = cfm;
+            row->lo = 0; row->hi = 1e30;
+            row->lam = lam0;
+        } else {
+            row->normal_row = first;
+            row->mu = mu;
+        }
+        srow_finish(s, row);
+    }
+    return first;
+}
+static void st_apply(const srow_t *r, real dl, real *st, real vb[ST_NOBJ][6]) {
+    if (r->arm >= 0)
+        for (int k = 0; k < 9; k++) st[K_QD + 9 * r->arm + k] += r->Ba[k] * dl;
+    if (r->bp >= 0)
+        for (int k = 0; k < 6; k++) vb[r->bp][k] += r->Bp[k] * dl;
+    if (r->bn >= 0)
+        for (int k = 0; k < 6; k++) vb[r->bn][k] += r->Bn[k] * dl;
+}
+
+/* ---- box/box manifold.  R row-major, column k = box axis k in the world.  Output: up to 4 points with the
+ * normal n pointing from B to A and the signed distance (negative = penetration).  Returns the point count. */
+typedef struct { real x, y, z; } cv_t;
+static int clip_axis(const cv_t *in, int n, cv_t *out, int axis, real sgn, real h) {
+    /* keep sgn * coord <= h */
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const cv_t *a = &in[i], *b = &in[(i + 1) % n];
+        real da = sgn * (axis == 0 ? a->x : a->y) - h, db = sgn * (axis == 0 ? b->x : b->y) - h;
+        if (da <= 0) out[m++] = *a;
+        if ((da <= 0) != (db <= 0)) {
+            real t = da / (da - db);
+            cv_t c = {a->x + t * (b->x - a->x), a->y + t * (b->y - a->y), a->z + t * (b->z - a->z)};
+            out[m++] = c;
+        }
+    }
+    return m;
+}
+static int box_box(const real *pA, const real *RA, const real *hA, const real *pB, const real *RB, const real *hB,
+                   real margin, real pts[4][3], real *nrm, real dist[4]) {
+    real A[3][3], B[3][3], t[3], tA[3], tB[3], C[3][3], Q[3][3];
+    for (int k = 0; k < 3; k++)
+        for (int r = 0; r < 3; r++) { A[k][r] = RA[r * 3 + k]; B[k][r] = RB[r * 3 + k]; }
+    v3_sub(t, pB, pA);
+    for (int i = 0; i < 3; i++) { tA[i] = v3_dot(A[i], t); tB[i] = v3_dot(B[i], t); }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { C[i][j] = v3_dot(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
+    /* face axes: code 0-2 = faces of A, 3-5 = faces of B */
+    real best = -1e30;
+    int code = -1;
+    for (int i = 0; i < 3; i++) {
+        real s = fabs(tA[i]) - (hA[i] + hB[0] * Q[i][0] + hB[1] * Q[i][1] + hB[2] * Q[i][2]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = i; }
+    }
+    for (int j = 0; j < 3; j++) {
+        real s = fabs(tB[j]) - (hB[j] + hA[0] * Q[0][j] + hA[1] * Q[1][j] + hA[2] * Q[2][j]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = 3 + j; }
+    }
+    /* edge axes A_i x B_j; an edge axis wins only when clearly better than the best face axis */
+    real ebest = -1e30, eaxis[3] = {0, 0, 0};
+    int ei = -1, ej = -1;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            real l2 = 1.0 - C[i][j] * C[i][j];
+            if (l2 < 1e-6) continue;
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            real l = sqrt(l2);
+            real expr = tA[i2] * C[i1][j] - tA[i1] * C[i2][j];
+            real ra = hA[i1] * Q[i2][j] + hA[i2] * Q[i1][j], rb = hB[j1] * Q[i][j2] + hB[j2] * Q[i][j1];
+            real s = (fabs(expr) - (ra + rb)) / l;
+            if (s > margin) return 0;
+            if (s > ebest) {
+                ebest = s; ei = i; ej = j;
+                real L[3];
+                v3_cross(L, A[i], B[j]);
+                real sg = expr < 0 ? -1.0 : 1.0;     /* orient from A to B */
+                v3_set(eaxis, sg * L[0] / l, sg * L[1] / l, sg * L[2] / l);
+            }
+        }
+    if (ei >= 0 && ebest - 1e-5 - 0.05 * fabs(ebest) > best) {
+        /* edge/edge: one point midway between the closest points of the two edges */
+        real pa[3], pb[3];
+        v3_copy(pa, pA);
+        v3_copy(pb, pB);
+        for (int k = 0; k < 3; k++) {
+            if (k != ei) v3_axpy(pa, (v3_dot(eaxis, A[k]) >= 0 ? 1.0 : -1.0) * hA[k], A[k]);
+            if (k != ej) v3_axpy(pb, (v3_dot(eaxis, B[k]) >= 0 ? -1.0 : 1.0) * hB[k], B[k]);
+        }
+        real p[3];
+        v3_sub(p, pb, pa);
+        real uaub = C[ei][ej], q1 = v3_dot(A[ei], p), q2 = -v3_dot(B[ej], p), dd = 1.0 - uaub * uaub;
+        real alpha = (q1 + uaub * q2) / dd, beta = (uaub * q1 + q2) / dd;
+        v3_axpy(pa, alpha, A[ei]);
+        v3_axpy(pb, beta, B[ej]);
+        for (int k = 0; k < 3; k++) { pts[0][k] = 0.5 * (pa[k] + pb[k]); nrm[k] = -eaxis[k]; }
+        dist[0] = ebest;
+        return 1;
+    }
+    /* face case: reference box R (the owner of the axis), incident box I */
+    int refA = code < 3, ri = refA ? code : code - 3;
+    const real(*Rx)[3] = refA ? A : B, (*Ix)[3] = refA ? B : A;
+    const real *pR = refA ? pA : pB, *pI = refA ? pB : pA, *hR = refA ? hA : hB, *hI = refA ? hB : hA;
+    real dR[3]; /* outward normal of the reference face, towards the incident box */
+    {
+        real sg = refA ? (tA[ri] < 0 ? -1.0 : 1.0) : (tB[ri] > 0 ? -1.0 : 1.0);
+        v3_set(dR, sg * Rx[ri][0], sg * Rx[ri][1], sg * Rx[ri][2]);
+    }
+    int jj = 0;
+    real bestdot = -1;
+    for (int j = 0; j < 3; j++) {
+        real d = fabs(v3_dot(Ix[j], dR));
+        if (d > bestdot) { bestdot = d; jj = j; }
+    }
+    real sj = v3_dot(Ix[jj], dR) > 0 ? -1.0 : 1.0;
+    int j1 = (jj + 1) % 3, j2 = (jj + 2) % 3, r1 = (ri + 1) % 3, r2 = (ri + 2) % 3;
+    cv_t poly[2][16];
+    int n = 4;
+    for (int v = 0; v < 4; v++) {
+        static const real su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+        real w[3];
+        for (int k = 0; k < 3; k++)
+            w[k] = pI[k] + sj * hI[jj] * Ix[jj][k] + su[v] * hI[j1] * Ix[j1][k] + sv[v] * hI[j2] * Ix[j2][k] - pR[k];
+        poly[0][v].x = v3_dot(w, Rx[r1]);
+        poly[0][v].y = v3_dot(w, Rx[r2]);
+        poly[0][v].z = v3_dot(w, dR) - hR[ri];
+    }
+    n = clip_axis(poly[0], n, poly[1], 0, 1.0, hR[r1]);
+    n = clip_axis(poly[1], n, poly[0], 0, -1.0, hR[r1]);
+    n = clip_axis(poly[0], n, poly[1], 1, 1.0, hR[r2]);
+    n = clip_axis(poly[1], n, poly[0], 1, -1.0, hR[r2]);
+    cv_t keep[16];
+    int nk = 0;
+    for (int i = 0; i < n; i++)
+        if (poly[0][i].z < margin) keep[nk++] = poly[0][i];
+    if (nk == 0) return 0;
+    int sel[4], ns = 0;
+    if (nk <= 4) {
+        for (int i = 0; i < nk; i++) sel[ns++] = i;
+    } else {
+        /* deepest point first, then the points closest to +90, +180, +270 degrees around the centroid */
+        real cx = 0, cy = 0;
+        int i0 = 0;
+        for (int i = 0; i < nk; i++) { cx += keep[i].x; cy += keep[i].y; if (keep[i].z < keep[i0].z) i0 = i; }
+        cx /= nk; cy /= nk;
+        real a0 = atan2(keep[i0].y - cy, keep[i0].x - cx);
+        int used[16] = {0};
+        used[i0] = 1;
+        sel[ns++] = i0;
+        for (int q = 1; q < 4; q++) {
+            real want = a0 + q * 1.5707963267948966;
+            int bi = -1;
+            real bd = 1e30;
+            for (int i = 0; i < nk; i++) {
+                if (used[i]) continue;
+                real a = atan2(keep[i].y - cy, keep[i].x - cx), d = fabs(remainder(a - want, 6.283185307179586));
+                if (d < bd) { bd = d; bi = i; }
+            }
+            used[bi] = 1;
+            sel[ns++] = bi;
+        }
+    }
+    for (int q = 0; q < ns; q++) {
+        const cv_t *v = &keep[sel[q]];
+        for (int k = 0; k < 3; k++) pts[q][k] = pR[k] + v->x * Rx[r1][k] + v->y * Rx[r2][k] + (v->z + hR[ri]) * dR[k];
+        dist[q] = v->z;
+    }
+    /* normal from B to A */
+    for (int k = 0; k < 3; k++) nrm[k] = refA ? -dR[k] : dR[k];
+    return ns;
+}
+int xo_box_box(const double *pA, const double *RA, const double *hA, const double *pB, const double *RB,
+               const double *hB, double margin, double *pts /*[4][3]*/, double *nrm, double *dist) {
+    real P[4][3];
+    int n = box_box(pA, RA, hA, pB, RB, hB, margin, P, nrm, dist);
+    memcpy(pts, P, sizeof P);
+    return n;
+}
+
+static void st_base(const xo_st_cfg *c, int arm, real *R, real *p) {
+    real rpy[3] = {0, 0, c->base_yaw[arm]};
+    m3_from_rpy(R, rpy);
+    v3_copy(p, c->base_pos[arm]);
+}
+
+static void st_substep(const xo_model *m, const xo_st_cfg *c, real *st, real dt) {
+    static const real finger_sign[2] = {1.0, -1.0};
+    static const int pair_a[ST_NPAIR] = {0, 0, 1}, pair_b[ST_NPAIR] = {1, 2, 2};
+    ssolver_t s;
+    s.m = m; s.c = c; s.nrows = 0;
+    s.imass = 1.0 / c->cube_mass;
+    s.iinertia = 1.0 / (c->cube_mass * 2.0 / 3.0 * c->cube_half * c->cube_half);  /* m/12 (2a)^2 * 2 */
+    for (int a = 0; a < 2; a++) {
+        real Rb[9], pb[3];
+        st_base(c, a, Rb, pb);
+        tree_setup_base(m, st + K_Q + 9 * a, &s.t[a], Rb, pb);
+    }
+    real vb[ST_NOBJ][6], Rc[ST_NOBJ][9];
+    const real h3[3] = {c->cube_half, c->cube_half, c->cube_half};
+    for (int o = 0; o < ST_NOBJ; o++) {
+        for (int k = 0; k < 3; k++) { vb[o][k] = st[K_BV + 3 * o + k]; vb[o][3 + k] = st[K_BW + 3 * o + k]; }
+        quat_to_m3(Rc[o], st + K_BQ + 4 * o);
+    }
+    /* unconstrained motion (isotropic cube inertia: no gyroscopic term) */
+    for (int a = 0; a < 2; a++) {
+        real tau[XO_MAXD] = {0}, qdd[XO_MAXD], *qd = st + K_QD + 9 * a;
+        for (int i = 0; i < m->n_links; i++)
+            if (s.t[a].dof[i] >= 0) tau[s.t[a].dof[i]] = -m->damping[i] * qd[s.t[a].dof[i]];
+        aba_forward_dynamics(m, &s.t[a], qd, tau, m->gravity, qdd);
+        for (int k = 0; k < 9; k++) qd[k] += dt * qdd[k];
+    }
+    {
+        real dl = pow(1.0 - m->lin_damping, dt), da = pow(1.0 - m->ang_damping, dt);
+        for (int o = 0; o < ST_NOBJ; o++) {
+            vb[o][2] -= dt * m->gravity;
+            for (int k = 0; k < 3; k++) { vb[o][k] *= dl; vb[o][k + 3] *= da; }
+        }
+    }
+    int row_t_n[ST_NOBJ * 8], row_p_n[8];
+    /* (T) cube corners against the table top */
+    for (int o = 0; o < ST_NOBJ; o++) {
+        const real *bp = st + K_BP + 3 * o;
+        int cnt = 0;
+        for (int i = 0; i < 8; i++) {
+            real rl[3] = {(i & 1) ? h3[0] : -h3[0], (i & 2) ? h3[1] : -h3[1], (i & 4) ? h3[2] : -h3[2]}, r[3], p[3];
+            m3_vec(r, Rc[o], rl);
+            v3_add(p, bp, r);
+            int on_table = fabs(p[0]) <= m->table_half_x && fabs(p[1]) <= m->table_half_y;
+            real dist = p[2] - m->table_top_z;
+            int active = on_table && dist < m->solver_margin && cnt < 4;
+            row_t_n[o * 8 + i] = -1;
+            if (!active) { st[K_LT + o * 8 + i] = 0; continue; }
+            cnt++;
+            real n[3] = {0, 0, 1};
+            row_t_n[o * 8 + i] = st_add_contact(&s, -1, -1, o, -1, bp, 0, p, n, dist, dt, m->contact_erp, 0.0,
+                                                m->mu_object * m->mu_table, m->warmstart * st[K_LT + o * 8 + i]);
+        }
+    }
+    /* (BB) cube / cube */
+    for (int pr = 0; pr < ST_NPAIR; pr++) {
+        int a = pair_a[pr], b = pair_b[pr];
+        real pts[4][3], n[3], dist[4];
+        int np = box_box(st + K_BP + 3 * a, Rc[a], h3, st + K_BP + 3 * b, Rc[b], h3, m->solver_margin, pts, n, dist);
+        for (int q = 0; q < np; q++)
+            st_add_contact(&s, -1, -1, a, b, st + K_BP + 3 * a, st + K_BP + 3 * b, pts[q], n, dist[q], dt, m->contact_erp, 0.0,
+                           m->mu_object * m->mu_object, 0.0);
+    }
+    /* (M)(L)(G) per arm */
+    for (int a = 0; a < 2; a++) {
+        real *q = st + K_Q + 9 * a, *qd = st + K_QD + 9 * a, *qt = st + K_QT + 9 * a;
+        tree_t *tr = &s.t[a];
+        for (int i = 0; i < m->n_links; i++) {
+            if (tr->dof[i] < 0) continue;
+            int d = tr->dof[i];
+            srow_t *r = srow_new(&s);
+            r->arm = a;
+            r->Ja[d] = 1;
+            r->vt = m->motor_kp * (qt[d] - q[d]) / dt + (1.0 - m->motor_kd) * qd[d];
+            real force = (m->jtype[i] == 2) ? c->finger_motor_force : m->arm_motor_force;
+            r->hi = force * c->time_step;
+            r->lo = -r->hi;
+            srow_finish(&s, r);
+        }
+        for (int i = 0; i < m->n_links; i++) {
+            if (tr->dof[i] < 0) continue;
+            int d = tr->dof[i];
+            for (int side = 0; side < 2; side++) {
+                real gap = side == 0 ? q[d] - m->lower[i] : m->upper[i] - q[d];
+                if (gap >= m->limit_window) continue;
+                srow_t *r = srow_new(&s);
+                r->arm = a;
+                r->Ja[d] = side == 0 ? 1.0 : -1.0;
+                r->vt = gap < 0 ? -m->global_erp * gap / dt : -gap / dt;
+                r->lo = 0; r->hi = 1e30;
+                srow_finish(&s, r);
+            }
+        }
+        {
+            int d1 = tr->dof[m->finger_link[0]], d2 = tr->dof[m->finger_link[1]];
+            srow_t *r = srow_new(&s);
+            r->arm = a;
+            r->Ja[d1] = 1.0;
+            r->Ja[d2] = -1.0;
+            r->vt = -m->gear_erp * m->global_erp * (q[d1] - q[d2]) / dt;
+            r->hi = m->gear_max_force * c->time_step;
+            r->lo = -r->hi;
+            srow_finish(&s, r);
+        }
+    }
+    /* (F) pads of arm 0, then of arm 1, each against its nearest cube */
+    {
+        real denom = dt * m->finger_contact_stiffness + m->finger_contact_damping + m->object_contact_damping;
+        real cfm = (1.0 / denom) / dt, erp = dt * m->finger_contact_stiffness / denom;
+        real mu = m->mu_object * m->mu_finger;
+        for (int a = 0; a < 2; a++)
+            for (int f = 0; f < 2; f++) {
+                int l = m->finger_link[f];
+                for (int j = 0; j < XO_NPAD; j++) {
+                    real cl[3] = {m->pad_center_left[j][0], finger_sign[f] * m->pad_center_left[j][1], m->pad_center_left[j][2]};
+                    real cw[3], bd = 1e30, bn[3] = {0, 0, 1}, bpnt[3] = {0, 0, 0};
+                    int bo = 0;
+                    m3_vec(cw, s.t[a].R[l], cl);
+                    v3_add(cw, cw, s.t[a].o[l]);
+                    for (int o = 0; o < ST_NOBJ; o++) {
+                        real dist, n[3], p[3];
+                        sphere_box(cw, m->pad_radius, st + K_BP + 3 * o, Rc[o], h3, m->contact_margin, &dist, n, p);
+                        if (dist < bd) { bd = dist; bo = o; v3_copy(bn, n); v3_copy(bpnt, p); }
+                    }
+                    int idx = a * 4 + f * XO_NPAD + j;
+                    row_p_n[idx] = -1;
+                    if (!(bd < m->solver_margin)) { st[K_LP + idx] = 0; continue; }
+                    row_p_n[idx] = st_add_contact(&s, a, l, -1, bo, 0, st + K_BP + 3 * bo, bpnt, bn, bd, dt, erp, cfm, mu,
+                                                  m->warmstart * st[K_LP + idx]);
+                }
+            }
+    }
+    /* warm start + PGS */
+    for (int k = 0; k < s.nrows; k++)
+        if (s.rows[k].lam != 0) st_apply(&s.rows[k], s.rows[k].lam, st, vb);
+    for (int it = 0; it < m->num_iterations; it++)
+        for (int k = 0; k < s.nrows; k++) {
+            srow_t *r = &s.rows[k];
+            if (r->normal_row >= 0) {
+                real lim = r->mu * s.rows[r->normal_row].lam;
+                r->lo = -lim; r->hi = lim;
+            }
+            real jv = 0;
+            if (r->arm >= 0) for (int cc = 0; cc < 9; cc++) jv += r->Ja[cc] * st[K_QD + 9 * r->arm + cc];
+            if (r->bp >= 0) for (int cc = 0; cc < 6; cc++) jv += r->Jp[cc] * vb[r->bp][cc];
+            if (r->bn >= 0) for (int cc = 0; cc < 6; cc++) jv += r->Jn[cc] * vb[r->bn][cc];
+            real dl = (r->vt - r->cfm * r->lam - jv) * r->inv_d, nl = r->lam + dl;
+            if (nl < r->lo) nl = r->lo;
+            if (nl > r->hi) nl = r->hi;
+            dl = nl - r->lam;
+            r->lam = nl;
+            st_apply(r, dl, st, vb);
+        }
+    for (int i = 0; i < ST_NOBJ * 8; i++)
+        if (row_t_n[i] >= 0) st[K_LT + i] = s.rows[row_t_n[i]].lam;
+    for (int i = 0; i < 8; i++)
+        if (row_p_n[i] >= 0) st[K_LP + i] = s.rows[row_p_n[i]].lam;
+    /* integrate */
+    for (int k = 0; k < 18; k++) st[K_Q + k] += dt * st[K_QD + k];
+    for (int o = 0; o < ST_NOBJ; o++) {
+        real *bp = st + K_BP + 3 * o, *bq = st + K_BQ + 4 * o;
+        for (int k = 0; k < 3; k++) bp[k] += dt * vb[o][k];
+        real w[3] = {vb[o][3], vb[o][4], vb[o][5]}, ang = v3_norm(w), ax[3];
+        if (ang * dt > 0.7853981633974483) ang = 0.7853981633974483 / dt;
+        real k = ang < 0.001 ? 0.5 * dt - dt * dt * dt * 0.020833333333 * ang * ang : sin(0.5 * ang * dt) / ang;
+        v3_set(ax, w[0] * k, w[1] * k, w[2] * k);
+        real cw = cos(ang * dt * 0.5), x = bq[0], y = bq[1], z = bq[2], w0 = bq[3];
+        real nx = cw * x + ax[0] * w0 + ax[1] * z - ax[2] * y, ny = cw * y + ax[1] * w0 + ax[2] * x - ax[0] * z;
+        real nz = cw * z + ax[2] * w0 + ax[0] * y - ax[1] * x, nw = cw * w0 - ax[0] * x - ax[1] * y - ax[2] * z;
+        real inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+        bq[0] = nx * inv; bq[1] = ny * inv; bq[2] = nz * inv; bq[3] = nw * inv;
+        for (int c2 = 0; c2 < 3; c2++) { st[K_BV + 3 * o + c2] = vb[o][c2]; st[K_BW + 3 * o + c2] = vb[o][c2 + 3]; }
+    }
+}
+static void st_tick(const xo_model *m, const xo_st_cfg *c, real *st) {
+    for (int k = 0; k < c->n_substeps; k++) st_substep(m, c, st, c->time_step / c->n_substeps);
+}
+
+static void st_arm_tree(const xo_model *m, const xo_st_cfg *c, int arm, const real *q9, tree_t *t) {
+    real Rb[9], pb[3], qin[XO_MAXD] = {0};
+    st_base(c, arm, Rb, pb);
+    memcpy(qin, q9, 9 * sizeof(real));
+    tree_setup_base(m, qin, t, Rb, pb);
+}
+static void st_obs(const xo_model *m, const xo_st_cfg *c, const real *st, real *obs, real *ag, real *dg) {
+    /* :190-199: obj_pos 9, obj_rot 12, obj_velp 9, obj_velr 9, then per arm grip_pos 3, grip_velp 3, finger q, qd */
+    for (int k = 0; k < 9; k++) { obs[k] = st[K_BP + k]; obs[21 + k] = st[K_BV + k]; obs[30 + k] = st[K_BW + k]; }
+    for (int k = 0; k < 12; k++) obs[9 + k] = st[K_BQ + k];
+    for (int a = 0; a < 2; a++) {
+        tree_t t;
+        st_arm_tree(m, c, a, st + K_Q + 9 * a, &t);
+        int l = m->hand_link, d1 = t.dof[m->finger_link[0]];
+        real cm[3], hp[3];
+        m3_vec(cm, t.R[l], m->com[l]);
+        v3_add(hp, t.o[l], cm);
+        for (int k = 0; k < 3; k++) {
+            real dd[3] = {0, 0, 0}, J[XO_MAXD], sum = 0;
+            dd[k] = 1;
+            point_jacobian_row(m, &t, l, hp, dd, J);
+            for (int j = 0; j < 9; j++) sum += J[j] * st[K_QD + 9 * a + j];
+            obs[39 + 8 * a + k] = hp[k];
+            obs[39 + 8 * a + 3 + k] = sum;
+        }
+        obs[39 + 8 * a + 6] = st[K_Q + 9 * a + d1];
+        obs[39 + 8 * a + 7] = st[K_QD + 9 * a + d1];
+    }
+    for (int k = 0; k < 9; k++) { ag[k] = st[K_BP + k]; dg[k] = st[K_GOAL + k]; }
+}
+/* draws 0-5: cube xy (cube i: 2i, 2i+1), 6-7: tower xy */
+static void st_draws(const xo_st_cfg *c, int64_t env, int64_t episode, real *u) {
+    uint32_t o[4];
+    uint64_t gid = (uint64_t)(c->env_id_offset + env);
+    for (int b = 0; b < 2; b++) {
+        xo_philox(c->seed, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)episode, (uint32_t)b, o);
+        for (int k = 0; k < 4; k++) u[b * 4 + k] = u01(o[k]);
+    }
+}
+static void st_sample_objects(const xo_st_cfg *c, const real *u, real *st) {
+    for (int o = 0; o < ST_NOBJ; o++) {
+        st[K_BP + 3 * o] = c->obj_low[0] + u[2 * o] * (c->obj_high[0] - c->obj_low[0]);
+        st[K_BP + 3 * o + 1] = c->obj_low[1] + u[2 * o + 1] * (c->obj_high[1] - c->obj_low[1]);
+        st[K_BP + 3 * o + 2] = c->height_offset;
+        st[K_BQ + 4 * o] = st[K_BQ + 4 * o + 1] = st[K_BQ + 4 * o + 2] = 0; st[K_BQ + 4 * o + 3] = 1;
+    }
+    for (int k = 0; k < 18; k++) st[K_BV + k] = 0;      /* K_BV and K_BW are adjacent */
+    for (int k = 0; k < 32; k++) st[K_LT + k] = 0;      /* K_LT and K_LP are adjacent */
+}
+static void st_sample_goal(const xo_st_cfg *c, const real *u, real *st) {
+    real x = c->goal_low[0] + u[6] * (c->goal_high[0] - c->goal_low[0]);
+    real y = c->goal_low[1] + u[7] * (c->goal_high[1] - c->goal_low[1]);
+    for (int o = 0; o < ST_NOBJ; o++) {                  /* :212-219 */
+        st[K_GOAL + 3 * o] = x; st[K_GOAL + 3 * o + 1] = y;
+        st[K_GOAL + 3 * o + 2] = c->height_offset * (2 * o + 1);
+    }
+}
+static void st_teleport_arms(const xo_st_cfg *c, real *st) {
+    for (int a = 0; a < 2; a++)
+        for (int k = 0; k < 9; k++) { st[K_Q + 9 * a + k] = c->joint_init_pos[k]; st[K_QD + 9 * a + k] = 0; }
+}
+int xo_st_init(const xo_model *m, const xo_st_cfg *c, int64_t E, double *state) {
+    (void)m;
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_ST_STATE_DIM, u[8];
+        memset(st, 0, XO_ST_STATE_DIM * sizeof(real));
+        st_teleport_arms(c, st);
+        for (int k = 0; k < 18; k++) st[K_QT + k] = st[K_Q + k];   /* no motor command yet: hold the init pose */
+        st_draws(c, e, 0, u);
+        st_sample_objects(c, u, st);
+        st_sample_goal(c, u, st);
+    }
+    return 0;
+}
+int xo_st_reset(const xo_model *m, const xo_st_cfg *c, int64_t E, double *state, const uint8_t *mask, double *obs,
+                double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        real *st = state + e * XO_ST_STATE_DIM, u[8];
+        int64_t episode = (int64_t)st[K_EPISODE] + 1;
+        st_teleport_arms(c, st);                       /* :203-205 */
+        st_draws(c, e, episode, u);
+        st_sample_objects(c, u, st);                   /* :207-209 */
+        st_tick(m, c, st);                             /* :210, with the motor targets of the last step still set */
+        st_sample_goal(c, u, st);
+        st[K_STEPS] = 0;
+        st[K_EPISODE] = (real)episode;
+        if (obs) st_obs(m, c, st, obs + e * XO_ST_OBS_DIM, ag + e * 9, dg + e * 9);
+    }
+    return 0;
+}
+int xo_st_compute_reward(const xo_st_cfg *c, int reward_type, int64_t n, const double *ag, const double *g, double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        real d2 = 0;
+        for (int k = 0; k < 9; k++) { real d = ag[i * 9 + k] - g[i * 9 + k]; d2 += d * d; }
+        real d = sqrt(d2);
+        out[i] = reward_type == 0 ? -(d > c->distance_threshold ? 1.0 : 0.0) : -d;   /* :124-129 */
+    }
+    return 0;
+}
+int xo_st_step(const xo_model *m, const xo_st_cfg *c, int64_t E, double *state, const double *actions, double *obs,
+               double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success) {
+    for (int64_t e = 0; e < E; e++) {
+        real *st = state + e * XO_ST_STATE_DIM;
+        const real *act = actions + e * XO_ST_ACT_DIM;
+        st[K_STEPS] += 1;
+        for (int a = 0; a < 2; a++) {
+            real av[4], tgt[3], qo[XO_MAXD], Rb[9], pb[3], qin[XO_MAXD] = {0};
+            tree_t t;
+            for (int k = 0; k < 4; k++) { real v = act[a * 4 + k]; av[k] = v < -1 ? -1 : (v > 1 ? 1 : v); }   /* :102 */
+            st_arm_tree(m, c, a, st + K_Q + 9 * a, &t);
+            for (int k = 0; k < 3; k++) {
+                real v = t.o[m->eef_link][k] + av[k] * c->max_vel * c->action_dt;
+                tgt[k] = v < c->pos_low[a][k] ? c->pos_low[a][k] : (v > c->pos_high[a][k] ? c->pos_high[a][k] : v);
+            }
+            real g = st[K_Q + 9 * a + 7] + av[3] * c->action_dt * c->max_gripper_vel;
+            g = g < c->gripper_low ? c->gripper_low : (g > c->gripper_high ? c->gripper_high : g);
+            st_base(c, a, Rb, pb);
+            memcpy(qin, st + K_Q + 9 * a, 9 * sizeof(real));
+            ik_solve_base(m, qin, tgt, c->n_substeps, qo, Rb, pb);   /* maxNumIterations = n_substeps, :154-155 */
+            for (int k = 0; k < 7; k++) st[K_QT + 9 * a + k] = qo[k];
+            st[K_QT + 9 * a + 7] = st[K_QT + 9 * a + 8] = g;
+        }
+        st_tick(m, c, st);
+        st_obs(m, c, st, obs + e * XO_ST_OBS_DIM, ag + e * 9, dg + e * 9);
+        real d2 = 0;
+        for (int k = 0; k < 9; k++) { real d = ag[e * 9 + k] - dg[e * 9 + k]; d2 += d * d; }
+        real dist = sqrt(d2);
+        success[e] = (uint8_t)(dist < c->distance_threshold);                    /* :221-223 */
+        reward[e] = c->reward_type == 0 ? -(dist > c->distance_threshold ? 1.0 : 0.0) : -dist;
+        done[e] = (uint8_t)((int)st[K_STEPS] == c->max_episode_steps);          /* step() itself never ends (:111) */
+    }
+    return 0;
+}

@@ -178,7 +178,36 @@ def handover():
     print("wrote handover_reward_reference.npz")
 
 
+def stack_tower():
+    """XarmStackTowerEnv.compute_reward (xarm_stack_tower.py:124-129: sparse -(d > 0.09) over the 9-vector, else -d)
+    and _is_success (:221-223) from the reference's own code, plus the tower goal layout of _sample_goal (:212-219)
+    evaluated with the reference's arithmetic (height_offset * (2 i + 1))."""
+    stub_modules()
+    spec = importlib.util.spec_from_file_location("ref_st", "/root/reference/gym_xarm/envs/xarm_stack_tower.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cls = mod.XarmStackTowerEnv
+    rng = np.random.default_rng(31337)
+    n = 512
+    xy = rng.uniform([-0.3, -0.2], [0.3, 0.2], size=(n, 2))
+    g = np.stack([np.concatenate((xy[i], [0.025 * (2 * k + 1)])) for i in range(n) for k in range(3)]).reshape(n, 9)
+    direction = rng.normal(size=(n, 9))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    radius = np.concatenate([rng.uniform(0, 0.5, n // 2), 0.09 + rng.uniform(-2e-3, 2e-3, n // 4), rng.uniform(0, 0.09, n - n // 2 - n // 4)])
+    ag = g + direction * radius[:, None]
+    out = {"achieved_goal": ag, "goal": g}
+    for rt in ("sparse", "dense"):
+        self = SimpleNamespace(reward_type=rt, distance_threshold=0.03 * 3)
+        out["reward_" + rt] = np.asarray(cls.compute_reward(self, ag, g, {}))
+        out["reward_single_" + rt] = np.array([cls.compute_reward(self, ag[i], g[i], {}) for i in range(64)])
+    out["is_success"] = np.array([cls._is_success(SimpleNamespace(goal=g[i], distance_threshold=0.09), ag[i], g[i]) for i in range(n)],
+                                 dtype=np.float32)
+    np.savez(os.path.join(OUT, "stack_reward_reference.npz"), **out)
+    print("wrote stack_reward_reference.npz")
+
+
 if __name__ == "__main__":
     main()
     reach()
     handover()
+    stack_tower()

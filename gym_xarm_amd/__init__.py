@@ -6,7 +6,7 @@ max_episode_steps)`) plus the IDs the reference's README/test.py name (README.md
 num_envs returns the single-env object with the reference's numpy call surface.
 """
 from . import _native  # noqa: F401
-from .vec_env import XarmPickAndPlaceVecEnv, XarmReachVecEnv, XarmHandoverVecEnv  # noqa: F401
+from .vec_env import XarmPickAndPlaceVecEnv, XarmReachVecEnv, XarmHandoverVecEnv, XarmStackTowerVecEnv  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -48,3 +48,7 @@ register("XarmReach-v0", "gym_xarm_amd.envs:XarmReachEnv", 25, "gym_xarm_amd.vec
 # gym_xarm/__init__.py:12-16 and its README / BASELINE.json alias
 for _id in ("XarmHandover-v0", "XarmPDHandover-v0"):
     register(_id, "gym_xarm_amd.envs:XarmHandover", 100, "gym_xarm_amd.vec_env:XarmHandoverVecEnv")
+# not in the reference's registry (the class exists, xarm_stack_tower.py:13, _max_episode_steps = 50 :43); BASELINE.json
+# config 4 names it XarmPDStackTower-v0
+for _id in ("XarmStackTower-v0", "XarmPDStackTower-v0"):
+    register(_id, "gym_xarm_amd.envs:XarmStackTowerEnv", 50, "gym_xarm_amd.vec_env:XarmStackTowerVecEnv")

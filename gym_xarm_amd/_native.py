@@ -10,6 +10,7 @@ XARM_OK = 0
 ENV_PICK_AND_PLACE = 0
 ENV_REACH = 1
 ENV_HANDOVER = 2
+ENV_STACK_TOWER = 3
 REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
 REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}

@@ -92,6 +92,8 @@ XARM_HD void xsincos(float x, float &s, float &c) { s = sinf(x); c = cosf(x); }
 XARM_HD void xsincos(double x, double &s, double &c) { s = sin(x); c = cos(x); }
 XARM_HD float xatan2(float y, float x) { return atan2f(y, x); }
 XARM_HD double xatan2(double y, double x) { return atan2(y, x); }
+XARM_HD float xremainder(float x, float y) { return remainderf(x, y); }
+XARM_HD double xremainder(double x, double y) { return remainder(x, y); }
 XARM_HD float xasin(float x) { return asinf(x); }
 XARM_HD double xasin(double x) { return asin(x); }
 XARM_HD float xabs(float x) { return fabsf(x); }
@@ -329,13 +331,16 @@ struct NoXchg {
 };
 
 // ---------------------------------------------------------------------------------------------
-// one internal substep (dt = timeStep / numSubSteps): collide, unconstrained dynamics, rows, PGS, integrate.
-// Dual-arm scenes run one arm per lane: `arm` selects the base frame, `xchg.from(a, v)` returns the copy of v
-// held by the lane of arm a of the same environment (object velocities are handed over between the two
-// finger/object phases of a sweep; everything else is either per-arm or computed identically by both lanes).
-template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg>
-XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
-    const T idt = (T)1 / dt;
+// Arm part of a substep, shared by every scene: FK, world-frame RNEA / CRBA, 9x9 Cholesky -> Minv, unconstrained
+// joint velocities, and the operational-space blocks S (hand Jacobian), T = Minv S^T, A_hh = S T staged in LDS.
+template <typename T> struct ArmDyn {
+    T Minv[45];        // packed lower 9x9
+    T dq[9];           // unconstrained joint velocities after dt
+    V3<T> hc0, hc1, hc2; // hand (link7) frame axes
+    V3<T> fo[2];       // finger frame origins
+};
+template <typename T, typename Lds, typename Scene>
+XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, const int arm, ArmDyn<T> &A) {
     // ---------------- kinematics + world-frame RNEA / CRBA
     SV<T> S[7];      // joint motion axes about the world origin
     RBI<T> Ib[9];    // per-body inertia, later suffix-summed into composite inertias
@@ -346,11 +351,11 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     acc.w = mk<T>(0, 0, 0); acc.v = mk<T>(0, 0, (T)xm::GRAVITY);
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        fk_advance(f, i, st.q[i]);
+        fk_advance(f, i, q_in[i]);
         S[i].w = f.c2;
         S[i].v = cross(f.o, f.c2);
         // acc += (vel_parent x S_i) qd_i ; vel += S_i qd_i
-        const T qd = st.qd[i];
+        const T qd = qd_in[i];
         acc.w = acc.w + cross(vel.w, S[i].w) * qd;
         acc.v = acc.v + (cross(vel.w, S[i].v) + cross(vel.v, S[i].w)) * qd;
         vel.w = vel.w + S[i].w * qd;
@@ -380,14 +385,15 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     }
     // hand frame = link7 frame; fingers slide along +/- hand y
     const V3<T> hc0 = f.c0, hc1 = f.c1, hc2 = f.c2, ho = f.o;
+    A.hc0 = hc0; A.hc1 = hc1; A.hc2 = hc2;
     const SV<T> vh = vel, ah = acc;
-    V3<T> fo[2]; // finger frame origins
+    V3<T> (&fo)[2] = A.fo; // finger frame origins
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const T sg = k == 0 ? (T)1 : (T)-1;
         const V3<T> af = hc1 * sg;
-        fo[k] = ho + hc2 * (T)xm::FINGER_Z + af * st.q[7 + k];
-        const T qd = st.qd[7 + k];
+        fo[k] = ho + hc2 * (T)xm::FINGER_Z + af * q_in[7 + k];
+        const T qd = qd_in[7 + k];
         SV<T> v = vh, a = ah;
         a.v = a.v + cross(vh.w, af) * qd;
         v.v = v.v + af * qd;
@@ -437,11 +443,11 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             SV<T> F = rbi_mul(Ic, S[j]);
 #pragma unroll
             for (int i = 0; i <= j; i++) M[tri(j, i)] = sdot(S[i], F);
-            tau[j] = -sdot(S[j], fc) - (T)xm::DAMPING[j] * st.qd[j];
+            tau[j] = -sdot(S[j], fc) - (T)xm::DAMPING[j] * qd_in[j];
         }
     }
     // Cholesky M = L L^T (in place), Linv, Minv = Linv^T Linv
-    T Minv[45];
+    T (&Minv)[45] = A.Minv;
     {
         T rd[9]; // reciprocals of the diagonal of L: one division per column instead of one per entry
 #pragma unroll
@@ -478,13 +484,13 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             }
     }
     // unconstrained joint velocities
-    T dq[9];
+    T (&dq)[9] = A.dq;
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         T s = (T)0;
 #pragma unroll
         for (int c = 0; c < 9; c++) s += Minv[symi(r, c)] * tau[c];
-        dq[r] = st.qd[r] + dt * s;
+        dq[r] = qd_in[r] + dt * s;
     }
     // T = Minv[:, 0:7] S^T (9 x 6) -> LDS; A_hh = S T_a (6x6 sym) -> registers; T_f rows -> registers
     {
@@ -524,6 +530,24 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             for (int k = 0; k < 6; k++) lds[LDS_T + r * 6 + k] = Tm[r][k];
         XARM_LDS_FENCE();
     }
+    (void)ho;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// one internal substep (dt = timeStep / numSubSteps): collide, unconstrained dynamics, rows, PGS, integrate.
+// Dual-arm scenes run one arm per lane: `arm` selects the base frame, `xchg.from(a, v)` returns the copy of v
+// held by the lane of arm a of the same environment (object velocities are handed over between the two
+// finger/object phases of a sweep; everything else is either per-arm or computed identically by both lanes).
+template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg>
+XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
+    const T idt = (T)1 / dt;
+    ArmDyn<T> AD;
+    arm_dynamics<T, Lds, Scene>(st.q, st.qd, dt, lds, arm, AD);
+    T (&Minv)[45] = AD.Minv;
+    T (&dq)[9] = AD.dq;
+    const V3<T> hc0 = AD.hc0, hc1 = AD.hc1, hc2 = AD.hc2;
+    const V3<T> (&fo)[2] = AD.fo;
 
     // ---------------- object: frame, inverse inertia, unconstrained motion
     V3<T> b0, b1, b2; // columns of Rb

@@ -23,6 +23,7 @@
 #include "xarm_core.h"
 #include "xarm_reach_core.h"
 #include "xarm_handover_core.h"
+#include "xarm_stack_core.h"
 
 namespace {
 
@@ -417,6 +418,145 @@ __global__ void k_ho_compute_reward(const float *__restrict__ ag, const float *_
     out[i] = sqrtf(dx * dx + dy * dy + dz * dz) > (float)xm::HO_DISTANCE_THRESHOLD ? -1.f : 0.f;
 }
 
+// --------------------------------------------------------------------- XarmPDStackTower-v0 (two lanes per env)
+// 423 LDS floats per lane = 108 KB per wavefront: one wavefront per CU, which is this scene's BASELINE size
+// (8192 envs per GPU = 256 wavefronts)
+__device__ __forceinline__ void st_load(const KParams &P, int64_t e, int arm, xs::Lane<float> &L) {
+    const float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        L.q[i] = S[(xs::K_Q + 9 * arm + i) * n]; L.qd[i] = S[(xs::K_QD + 9 * arm + i) * n]; L.qt[i] = S[(xs::K_QT + 9 * arm + i) * n];
+    }
+#pragma unroll
+    for (int o = 0; o < xs::NOBJ; o++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            L.bp[o][k] = S[(xs::K_BP + 3 * o + k) * n]; L.bv[o][k] = S[(xs::K_BV + 3 * o + k) * n];
+            L.bw[o][k] = S[(xs::K_BW + 3 * o + k) * n]; L.goal[o][k] = S[(xs::K_GOAL + 3 * o + k) * n];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) L.bq[o][k] = S[(xs::K_BQ + 4 * o + k) * n];
+#pragma unroll
+        for (int k = 0; k < 8; k++) L.lam_t[o][k] = S[(xs::K_LT + 8 * o + k) * n];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) L.lam_p[k] = S[(xs::K_LP + 4 * arm + k) * n];
+    L.steps = S[xs::K_STEPS * n]; L.episode = S[xs::K_EPISODE * n];
+}
+__device__ __forceinline__ void st_store(const KParams &P, int64_t e, int arm, const xs::Lane<float> &L) {
+    float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        S[(xs::K_Q + 9 * arm + i) * n] = L.q[i]; S[(xs::K_QD + 9 * arm + i) * n] = L.qd[i]; S[(xs::K_QT + 9 * arm + i) * n] = L.qt[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) S[(xs::K_LP + 4 * arm + k) * n] = L.lam_p[k];
+    if (arm == 0) { // shared fields are bit-identical in both lanes
+#pragma unroll
+        for (int o = 0; o < xs::NOBJ; o++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                S[(xs::K_BP + 3 * o + k) * n] = L.bp[o][k]; S[(xs::K_BV + 3 * o + k) * n] = L.bv[o][k];
+                S[(xs::K_BW + 3 * o + k) * n] = L.bw[o][k]; S[(xs::K_GOAL + 3 * o + k) * n] = L.goal[o][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) S[(xs::K_BQ + 4 * o + k) * n] = L.bq[o][k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) S[(xs::K_LT + 8 * o + k) * n] = L.lam_t[o][k];
+        }
+        S[xs::K_STEPS * n] = L.steps; S[xs::K_EPISODE * n] = L.episode;
+    }
+}
+// observation (:190-199): cube pos 9, quat 12, v 9, w 9, then per arm hand COM pos 3, vel 3, finger q, qd
+__device__ __forceinline__ void st_write_obs(const xs::Lane<float> &L, int64_t e, int arm, float *obs_out, float *ag_out, float *dg_out) {
+    float o8[8];
+    xs::arm_obs(L, arm, o8);
+    float *o = obs_out + e * xs::OBS_DIM;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[39 + 8 * arm + k] = o8[k];
+    if (arm == 0) {
+#pragma unroll
+        for (int ob = 0; ob < xs::NOBJ; ob++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                o[3 * ob + k] = L.bp[ob][k]; o[21 + 3 * ob + k] = L.bv[ob][k]; o[30 + 3 * ob + k] = L.bw[ob][k];
+                if (ag_out) { ag_out[e * 9 + 3 * ob + k] = L.bp[ob][k]; dg_out[e * 9 + 3 * ob + k] = L.goal[ob][k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[9 + 4 * ob + k] = L.bq[ob][k];
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_st_init(KParams P) {
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e = t >> 1;
+    const int arm = (int)(t & 1);
+    if (e >= P.num_envs) return;
+    xs::Lane<float> L;
+    xs::lane_init<float>(P.cfg, e, L);
+    st_store(P, e, arm, L);
+}
+__global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                int *__restrict__ done_list, int *__restrict__ done_count,
+                                                int *__restrict__ stale_count) {
+    __shared__ float smem[xs::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int arm = (int)(t & 1);
+    if (t == 0 && stale_count) *stale_count = 0;
+    if (e_in >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xs::Lane<float> L;
+    st_load(P, e_in, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float reward;
+    bool done, success;
+    xs::lane_step<float, DevLds, DppXchg>(P.cfg, L, arm, act, reward, done, success, lds, DppXchg());
+    const int64_t e = late_index(e_in);
+    st_store(P, e, arm, L);
+    st_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+    if (done && P.auto_reset && term_obs) st_write_obs(L, e, arm, term_obs, nullptr, nullptr);
+    if (arm == 0) {
+        rew_out[e] = reward;
+        done_out[e] = done ? 1 : 0;
+        succ_out[e] = success ? 1 : 0;
+        if (done && P.auto_reset) {
+            const int pos = atomicAdd(done_count, 1);
+            done_list[pos] = (int)e;
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_st_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                 float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+    __shared__ float smem[xs::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
+    const int arm = (int)(t & 1);
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (i >= n) return;
+    const int64_t e_in = list ? (int64_t)list[i] : i;
+    DevLds lds{smem + threadIdx.x};
+    xs::Lane<float> L;
+    st_load(P, e_in, arm, L);
+    xs::lane_reset<float, DevLds, DppXchg>(P.cfg, e_in, L, arm, lds, DppXchg());
+    const int64_t e = late_index(e_in);
+    st_store(P, e, arm, L);
+    if (obs_out) st_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+}
+// xarm_stack_tower.py:124-129 over n rows of 9
+__global__ void k_st_compute_reward(int reward_type, const float *__restrict__ ag, const float *__restrict__ g, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const float d = ag[i * 9 + k] - g[i * 9 + k]; d2 += d * d; }
+    const float d = sqrtf(d2);
+    out[i] = reward_type == 0 ? (d > (float)xm::ST_DISTANCE_THRESHOLD ? -1.f : 0.f) : -d;
+}
+
 // number of steps taken in the current episode (info['future_length'] = max_episode_steps - steps, :90)
 __global__ void k_episode_steps(KParams P, int steps_field, int32_t *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,13 +617,15 @@ const char *xarm_last_error(const xarm_handle *h) { return h ? h->err : g_err; }
 
 int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (!cfg || !out) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: null argument");
-    const bool reach = cfg->env_kind == XARM_ENV_REACH, handover = cfg->env_kind == XARM_ENV_HANDOVER;
-    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach && !handover) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
-    if (!reach && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
+    const bool reach = cfg->env_kind == XARM_ENV_REACH, handover = cfg->env_kind == XARM_ENV_HANDOVER, stack = cfg->env_kind == XARM_ENV_STACK_TOWER;
+    if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach && !handover && !stack) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
+    if (stack && cfg->num_obj != 3) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower has num_obj == 3 (xarm_stack_tower.py:19)");
+    if (stack && cfg->reward_type > 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower reward_type is 0 (sparse) or 1 (-d)");
+    if (!reach && !stack && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
     if (handover && cfg->reward_type != 0) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover is sparse-only (reward_type is hard-wired, xarm_handover.py:40)");
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
     if (cfg->reward_type < 0 || cfg->reward_type > 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
-    if (!reach && cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
+    if (!reach && !stack && cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported goal_shape");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, XARM_E_NODEVICE, "%s", "xarm_create: no HIP device");
@@ -503,7 +645,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.cfg.goal_shape = cfg->goal_shape;
     h->kp.cfg.reward_type = cfg->reward_type;
     h->kp.auto_reset = cfg->auto_reset;
-    h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : xk::STATE_DIM);
+    h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
     h->kp.hcfg.same_side_rate = cfg->same_side_rate;
@@ -525,6 +667,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     hipMemset(h->mask_count, 0, sizeof(int));
     if (reach) k_reach_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
     else if (handover) k_ho_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
+    else if (stack) k_st_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
     else k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
     hipError_t e5 = hipDeviceSynchronize();
     if (e5 != hipSuccess) {
@@ -552,12 +695,13 @@ int xarm_destroy(xarm_handle *h) {
 int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
     if (!out) return XARM_E_INVALID;
     const bool reach = h && h->cfg.env_kind == XARM_ENV_REACH, handover = h && h->cfg.env_kind == XARM_ENV_HANDOVER;
-    out->obs_dim = reach ? xr::OBS_DIM : (handover ? xh::OBS_DIM : xk::OBS_DIM);
-    out->goal_dim = xk::GOAL_DIM;
-    out->act_dim = handover ? xh::ACT_DIM : xk::ACT_DIM;
-    out->state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : xk::STATE_DIM);
-    out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : (handover ? xm::HO_MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS);
-    out->n_substeps = reach ? xmr::N_SUBSTEPS : (handover ? xm::HO_N_TICKS : xm::PNP_N_SUBSTEPS);
+    const bool stack = h && h->cfg.env_kind == XARM_ENV_STACK_TOWER;
+    out->obs_dim = reach ? xr::OBS_DIM : (handover ? xh::OBS_DIM : (stack ? xs::OBS_DIM : xk::OBS_DIM));
+    out->goal_dim = stack ? xs::GOAL_DIM : xk::GOAL_DIM;
+    out->act_dim = handover ? xh::ACT_DIM : (stack ? xs::ACT_DIM : xk::ACT_DIM);
+    out->state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
+    out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : (handover ? xm::HO_MAX_EPISODE_STEPS : (stack ? xm::ST_MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS));
+    out->n_substeps = reach ? xmr::N_SUBSTEPS : (handover ? xm::HO_N_TICKS : (stack ? xm::ST_N_SUBSTEPS : xm::PNP_N_SUBSTEPS));
     return XARM_OK;
 }
 
@@ -571,10 +715,12 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
     } else {
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
     }
     HIPCHK(h, hipGetLastError());
@@ -593,7 +739,11 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (timed && h->ev_n == xarm_handle::NEV) timing_flush(h);
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
     const bool reach = h->cfg.env_kind == XARM_ENV_REACH, handover = h->cfg.env_kind == XARM_ENV_HANDOVER;
-    if (handover)
+    const bool stack = h->cfg.env_kind == XARM_ENV_STACK_TOWER;
+    if (stack)
+        k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                       terminal_obs_dev, h->done_list, cnt, stale);
+    else if (handover)
         k_ho_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                        terminal_obs_dev, h->done_list, cnt, stale);
     else if (reach)
@@ -606,6 +756,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (h->kp.auto_reset) {
         if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else if (handover) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
     }
     h->step_index++;
@@ -616,6 +767,12 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
 int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
     if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
+    if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) {
+        if (n == 0) return XARM_OK;
+        k_st_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->cfg.reward_type, ag_dev, g_dev, n, out_dev);
+        HIPCHK(h, hipGetLastError());
+        return XARM_OK;
+    }
     if (h->cfg.env_kind == XARM_ENV_HANDOVER) {
         if (n == 0) return XARM_OK;
         k_ho_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
@@ -655,7 +812,8 @@ int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
 
 int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
     if (!h || !steps_dev) return XARM_E_INVALID;
-    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (int)xh::H_STEPS : (int)xk::S_STEPS);
+    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (int)xh::H_STEPS :
+                      (h->cfg.env_kind == XARM_ENV_STACK_TOWER ? (int)xs::K_STEPS : (int)xk::S_STEPS));
     k_episode_steps<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, field, steps_dev);
     HIPCHK(h, hipGetLastError());
     return XARM_OK;

@@ -318,3 +318,42 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
 
     def debug_substeps(self, q_target, n):
         raise NotImplementedError
+
+
+# the reference's XarmStackTowerEnv takes no config (xarm_stack_tower.py:14); reward_type is an attribute (:28)
+STACK_CONFIG_DEFAULTS = {"GUI": False, "num_obj": 3, "reward_type": "sparse"}
+
+
+class XarmStackTowerVecEnv(XarmPickAndPlaceVecEnv):
+    """E independent XarmPDStackTower-v0 environments (/root/reference/gym_xarm/envs/xarm_stack_tower.py:13): two
+    xArm7 + Panda-gripper arms and three 5 cm cubes on one table; obs 55 (:190-199), action 8 (:86), goal 9 =
+    tower positions (:212-219), reward -(|ag - g| > 0.09) or -d (:124-129), 50 steps (:43).  step() of the reference
+    never sets done (:111); the VecEnv reports the 50-step limit as done with TimeLimit.truncated."""
+
+    ENV_KIND = _native.ENV_STACK_TOWER
+    AG_SLICE = slice(0, 9)    # achieved_goal = the three cube positions, first in the observation (:190)
+
+    def _check_config(self, config):
+        cfg = dict(STACK_CONFIG_DEFAULTS)
+        cfg.update(config or {})
+        if cfg["num_obj"] != 3:
+            raise NotImplementedError("XarmStackTower has num_obj == 3 (xarm_stack_tower.py:19)")
+        if cfg["reward_type"] not in ("sparse", "dense"):
+            raise NotImplementedError("reward_type %r" % (cfg["reward_type"],))
+        return cfg
+
+    def _native_config(self):
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 3,
+                                  0 if self.config["reward_type"] == "sparse" else 1, 0, 0.0, 0.0, int(self._auto_reset),
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0, 0)
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.distance_threshold = 0.03 * 3   # :20-21
+
+    def _extra_info(self, info):
+        info["TimeLimit.truncated"] = self._done != 0   # only the step limit ends an episode
+
+    def debug_substeps(self, q_target, n):
+        raise NotImplementedError
+

@@ -42,6 +42,9 @@ extern "C" {
 #define XARM_ENV_HANDOVER 2       /* XarmHandover-v0 / XarmPDHandover-v0 (xarm_handover.py): two arms, one stick,
                                      obs 29, action 8, sparse reward -1/0, 100 steps; uses same_side_rate and
                                      goal_shape (XARM_GOAL_GROUND = 'ground', else the sampled height) */
+#define XARM_ENV_STACK_TOWER 3    /* XarmPDStackTower-v0 (xarm_stack_tower.py): two arms, three cubes (num_obj = 3),
+                                     obs 55, action 8, goal 9, reward_type 0 = -(d > 0.09) / 1 = -d (:124-129),
+                                     50 steps (:43); step() itself never reports done (:111) */
 
 #define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
 #define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */

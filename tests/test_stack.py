@@ -1,0 +1,257 @@
+"""XarmPDStackTower-v0: the kernel core (gym_xarm_amd/csrc/xarm_stack_core.h) against the CPU oracle - host (g++)
+instantiation in float64/float32 on the CPU, the HIP path through the C-ABI on the GPU.  Physics parity against
+PyBullet is UNPINNED (PyBullet absent); the reward arithmetic is pinned by the reference's NumPy code
+(tests/golden/stack_reward_reference.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CONT = np.r_[0:36, 54:93]          # q, qd of both arms, cube poses and velocities
+POS = np.r_[0:18, 54:75]           # joint positions, cube positions and quaternions
+
+
+def rot(ax, a):
+    c, s = np.cos(a), np.sin(a)
+    return {0: np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), 1: np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+            2: np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[ax]
+
+
+def perturb(state, rng, eps=1e-6):
+    s = np.array(state, dtype=np.float64, copy=True)
+    s[:, CONT] += rng.uniform(-eps, eps, size=(s.shape[0], CONT.size))
+    for o in range(3):
+        q = s[:, 63 + 4 * o:67 + 4 * o]
+        s[:, 63 + 4 * o:67 + 4 * o] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return s
+
+
+def oracle_step_with_sens(ora, state, actions, seed=0):
+    rng = np.random.default_rng(seed)
+    ora.set_state(state)
+    out = ora.step(actions)
+    nxt = ora.get_state()
+    sens = np.zeros(state.shape[0])
+    for _ in range(2):
+        ora.set_state(perturb(state, rng))
+        ora.step(actions)
+        sens = np.maximum(sens, np.abs(ora.get_state()[:, CONT] - nxt[:, CONT]).max(axis=1))
+    ora.set_state(nxt)
+    return (nxt,) + tuple(out) + (sens,)
+
+
+@pytest.fixture(scope="module")
+def host():
+    from conftest import HostCore
+    return HostCore()
+
+
+def test_cube_cube_host_matches_oracle(oracle, host):
+    rng = np.random.default_rng(5)
+    h3 = np.full(3, 0.025)
+    hits = 0
+    for i in range(600):
+        if i % 3 == 0:   # yaw-only poses: the face/face configurations of cubes lying on a table or on each other
+            RA, RB = rot(2, rng.uniform(-3, 3)), rot(2, rng.uniform(-3, 3))
+        else:
+            RA = rot(0, rng.uniform(-3, 3)) @ rot(1, rng.uniform(-3, 3)) @ rot(2, rng.uniform(-3, 3))
+            RB = rot(2, rng.uniform(-3, 3)) @ rot(0, rng.uniform(-3, 3))
+        pA, pB = rng.uniform(-0.04, 0.04, 3), rng.uniform(-0.04, 0.04, 3)
+        p, n, d = oracle.box_box(pA, RA, h3, pB, RB, h3, 0.005)
+        p2, n2, d2 = host.cube_cube(pA, RA, pB, RB, f32=0)
+        assert len(p) == len(p2)
+        if len(p):
+            hits += 1
+            assert np.allclose(p, p2, atol=1e-12) and np.allclose(n, n2, atol=1e-12) and np.allclose(d, d2, atol=1e-12)
+            p3, n3, d3 = host.cube_cube(pA, RA, pB, RB, f32=1)
+            if len(p3) == len(p) and np.allclose(n, n3, atol=1e-3):   # float32 may break a tie the other way
+                assert abs(d3.min() - d.min()) < 1e-5
+    assert hits > 400
+
+
+def test_stack_host_f64_matches_oracle(oracle, host):
+    E = 3
+    ora = oracle.OracleStackTower(E, seed=4)
+    st = host.st_init(E, f32=0, seed=4)
+    assert np.array_equal(st, ora.get_state())
+    st, obs, ag, dg = host.st_reset(st, f32=0, seed=4)
+    o2, a2, d2 = ora.reset()
+    assert np.abs(st - ora.get_state()).max() < 1e-12 and np.abs(obs - o2).max() < 1e-12 and np.array_equal(dg, d2)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        act = rng.uniform(-1.2, 1.2, (E, 8))
+        st, obs, ag, dg, rew, done, succ = host.st_step(st, act, f32=0, seed=4)
+        o2, a2, d2, r2, dn2, s2 = ora.step(act)
+        assert np.abs(st - ora.get_state()).max() < 1e-10 and np.abs(obs - o2).max() < 1e-10
+        assert np.array_equal(rew, r2) and np.array_equal(done, dn2) and np.array_equal(succ, s2)
+
+
+def test_stack_host_f64_contact_scenarios(oracle, host):
+    """overlapping spawn (cube/cube rows), a standing tower, and a cube inside a closing gripper"""
+    ora = oracle.OracleStackTower(3, seed=2)
+    s = ora.get_state()
+    s[0, 54:63] = [0.0, 0.0, 0.025, 0.03, 0.004, 0.025, 0.2, 0.1, 0.025]
+    s[1, 54:63] = [0.1, 0.05, 0.025, 0.1, 0.05, 0.075, 0.103, 0.048, 0.125]
+    s[1, 67:71] = [0, 0, np.sin(0.3), np.cos(0.3)]                          # middle cube yawed
+    ora.set_state(s)
+    ora.step(np.zeros((3, 8)))
+    # env 2: put cube 0 between the pads of arm 1
+    obs = ora.step(np.zeros((3, 8)))[0]
+    s = ora.get_state()
+    s[2, 54:57] = obs[2, 39:42] - [0, 0, 0.067]
+    s[2, 75:93] = 0
+    ora.set_state(s)
+    st = ora.get_state()
+    act = np.zeros((3, 8))
+    act[2, 3] = -1
+    for _ in range(3):
+        st, obs, ag, dg, rew, done, succ = host.st_step(st, act, f32=0, seed=2)
+        o2 = ora.step(act)[0]
+        assert np.abs(st - ora.get_state()).max() < 1e-9, np.abs(st - ora.get_state()).max(0).argmax()
+    assert st[2, 126:130].max() > 0, "the gripper scenario produced no pad contact"
+    assert abs(st[1, 56 + 6] - 0.125) < 2e-3          # the tower still stands
+
+
+def test_stack_host_f32_close_to_oracle(oracle, host):
+    E = 4
+    ora = oracle.OracleStackTower(E, seed=9)
+    st = ora.get_state()
+    rng = np.random.default_rng(3)
+    act = rng.uniform(-1, 1, (E, 8))
+    nxt, o2, a2, d2, r2, dn2, s2, sens = oracle_step_with_sens(ora, st, act)
+    st32, obs, ag, dg, rew, done, succ = host.st_step(st, act, f32=1, seed=9)
+    err = np.abs(st32[:, POS] - nxt[:, POS]).max(axis=1)
+    assert np.all(err < 5e-4 + 300 * sens), (err, sens)
+    assert np.array_equal(rew, r2)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _make(E, **kw):
+    import gym_xarm_amd
+    return gym_xarm_amd.make("XarmPDStackTower-v0", num_envs=E, **kw)
+
+
+@pytest.mark.gpu
+def test_stack_gpu_dims_and_reset_parity(oracle):
+    import torch
+    E = 128
+    env = _make(E, seed=4, auto_reset=False)
+    assert (env.obs_dim, env.goal_dim, env.act_dim, env.state_dim, env.max_episode_steps) == (55, 9, 8, 136, 50)
+    assert env.action_space.shape == (8,) and env.observation_space["observation"].shape == (55,)
+    ora = oracle.OracleStackTower(E, seed=4)
+    assert np.abs(env.get_state().cpu().numpy() - ora.get_state()).max() < 1e-6
+    obs = env.reset()
+    o2, a2, d2 = ora.reset()
+    sd = np.abs(env.get_state().cpu().numpy() - ora.get_state())
+    assert sd[:, POS].max() < 5e-4, sd[:, POS].max()
+    assert np.abs(obs["desired_goal"].cpu().numpy() - d2).max() < 1e-6
+    assert np.abs(obs["achieved_goal"].cpu().numpy() - a2).max() < 5e-4
+    assert torch.equal(obs["observation"][:, 0:9], obs["achieved_goal"])
+    env.close()
+
+
+@pytest.mark.gpu
+def test_stack_gpu_step_parity_with_sensitivity(oracle, parity):
+    import torch
+    E = 256
+    env = _make(E, seed=6, auto_reset=False)
+    env.reset()
+    ora = oracle.OracleStackTower(E, seed=6)
+    rng = np.random.default_rng(2)
+    # spread a few envs into contact-rich states: overlapping cubes, a tower, a cube under a gripper
+    s = env.get_state().cpu().numpy().astype(np.float64)
+    s[0:32, 57:60] = s[0:32, 54:57] + [0.03, 0.004, 0.0]
+    s[32:64, 57:60] = s[32:64, 54:57] + [0.002, -0.001, 0.05]
+    s[32:64, 60:63] = s[32:64, 54:57] + [0.0, 0.002, 0.10]
+    env.set_state(torch.tensor(s, dtype=torch.float32))
+    worst = {}
+    for k in range(6):
+        st = env.get_state().cpu().numpy().astype(np.float64)
+        act = rng.uniform(-1, 1, (E, 8)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act))
+        nxt, o2, a2, d2, r2, dn2, s2, sens = oracle_step_with_sens(ora, st, act.astype(np.float64), seed=k)
+        dev = env.get_state().cpu().numpy()
+        stats = parity.compare(dev[:, CONT], nxt[:, CONT], sens, frac_tight=0.7, max_exempt=0.15, what="StackTower state step %d" % k)
+        parity.compare(obs["observation"].cpu().numpy(), o2, sens, frac_tight=0.7, max_exempt=0.15, what="StackTower obs step %d" % k)
+        ok = sens < 1e-6
+        assert np.array_equal(rew.cpu().numpy()[ok], r2[ok].astype(np.float32))
+        assert np.array_equal(done.cpu().numpy(), dn2)
+        worst = stats
+    assert worst["frac_tight"] >= 0.7
+    env.close()
+
+
+@pytest.mark.gpu
+def test_stack_gpu_scripted_pick_and_stack(oracle):
+    """the behaviour the env exists for, on the HIP path: arm 1 picks cube 0 and puts it on cube 1"""
+    import torch
+    env = _make(1, seed=1, auto_reset=False)
+    s = env.get_state()
+    s[0, 54:63] = torch.tensor([-0.2, 0, 0.025, 0.0, 0.1, 0.025, 0.2, -0.1, 0.025], device=env.device)
+    env.set_state(s)
+    o = env.step(torch.zeros(1, 8))[0]["observation"].cpu().numpy()
+
+    def servo(xy, z, g, n):
+        nonlocal o
+        for _ in range(n):
+            hp = o[0, 39:42]
+            a = np.zeros((1, 8), np.float32)
+            a[0, 0:2] = np.clip((np.asarray(xy) - hp[:2]) / 0.0625, -1, 1)
+            a[0, 2] = np.clip((z - hp[2]) / 0.0625, -1, 1)
+            a[0, 3] = g
+            o = env.step(torch.from_numpy(a))[0]["observation"].cpu().numpy()
+
+    servo([-0.2, 0], 0.25, 1, 12); servo([-0.2, 0], 0.085, 1, 12); servo([-0.2, 0], 0.085, -1, 6); servo([-0.2, 0], 0.25, -1, 10)
+    assert o[0, 2] > 0.15, "cube 0 was not lifted"
+    servo([0.0, 0.1], 0.25, -1, 14); servo([0.0, 0.1], 0.139, -1, 10); servo([0.0, 0.1], 0.139, 1, 6); servo([0.0, 0.1], 0.3, 1, 8)
+    c = o[0, 0:9].reshape(3, 3)
+    assert abs(c[0, 2] - 0.075) < 1e-3 and abs(c[1, 2] - 0.025) < 1e-3 and np.linalg.norm(c[0, :2] - c[1, :2]) < 0.02, c
+    env.close()
+
+
+@pytest.mark.gpu
+def test_stack_gpu_reward_kernel_matches_reference_numpy():
+    import torch
+    d = np.load(os.path.join(GOLDEN, "stack_reward_reference.npz"))
+    ag, g = torch.tensor(d["achieved_goal"], dtype=torch.float32), torch.tensor(d["goal"], dtype=torch.float32)
+    dist = np.linalg.norm(d["achieved_goal"] - d["goal"], axis=1)
+    clear = np.abs(dist - 0.09) > 1e-5          # float32 vs float64 exactly on the threshold shell
+    for rt in ("sparse", "dense"):
+        env = _make(4, config={"reward_type": rt})
+        out = env.compute_reward(ag, g).cpu().numpy()
+        if rt == "sparse":
+            assert np.array_equal(out[clear], d["reward_sparse"][clear])          # xarm_stack_tower.py:124-127
+        else:
+            assert np.allclose(out, d["reward_dense"], atol=1e-6)                 # :128-129
+        env.close()
+
+
+@pytest.mark.gpu
+def test_stack_gpu_time_limit_autoreset_and_sharding():
+    import torch
+    E = 96
+    env = _make(E, seed=21)
+    obs = env.reset()
+    g0 = obs["desired_goal"].clone()
+    gen = torch.Generator(device=env.device)
+    gen.manual_seed(0)
+    for k in range(50):
+        obs, rew, done, info = env.step(torch.rand(E, 8, device=env.device, generator=gen) * 2 - 1)
+        assert bool((done != 0).all()) == (k == 49) and bool((done != 0).any()) == (k == 49)
+        assert torch.isfinite(obs["observation"]).all()
+    assert bool(info["TimeLimit.truncated"].all())
+    assert int(env.episode_steps().max()) == 0                     # auto-reset happened inside the call
+    assert not torch.equal(obs["desired_goal"], g0)                # a fresh tower goal per episode
+    # freshly respawned cubes are upright unless two of them spawned overlapping (no rejection sampling, :207-209)
+    upright = (obs["observation"][:, 9:21].reshape(E, 3, 4) - torch.tensor([0., 0., 0., 1.], device=env.device)).abs().amax(dim=(1, 2)) < 1e-3
+    assert float(upright.float().mean()) > 0.8
+    term = info["terminal_observation"]
+    assert not torch.allclose(term[:, 0:9], obs["observation"][:, 0:9])
+    # the same global env ids on a shard give the same episodes
+    shard = _make(32, seed=21, env_id_offset=64)
+    full = _make(E, seed=21)
+    a, b = shard.reset(), full.reset()
+    assert torch.equal(a["desired_goal"], b["desired_goal"][64:96]) and torch.allclose(a["observation"], b["observation"][64:96], atol=0)
+    for e in (env, shard, full):
+        e.close()

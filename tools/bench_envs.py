@@ -2,7 +2,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gym_xarm_amd
-for env_id, E, A, steps in (("XarmReach-v0", 4096, 4, 100), ("XarmReach-v0", 65536, 4, 100), ("XarmPDHandover-v0", 16384, 8, 60), ("XarmPDHandover-v0", 32768, 8, 60)):
+for env_id, E, A, steps in (("XarmReach-v0", 4096, 4, 100), ("XarmReach-v0", 65536, 4, 100), ("XarmPDHandover-v0", 16384, 8, 60), ("XarmPDHandover-v0", 32768, 8, 60),
+                           ("XarmPDStackTower-v0", 8192, 8, 60), ("XarmPDStackTower-v0", 16384, 8, 60)):
     env = gym_xarm_amd.make(env_id, num_envs=E, seed=0)
     env.reset()
     acts = [torch.rand(E, A, device="cuda") * 2 - 1 for _ in range(8)]

@@ -32,6 +32,9 @@
 #define XARM_HD __device__ __forceinline__
 // wave-uniform "does any lane need this block" (64-wide ballot)
 #define XARM_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
+// same ballot, for decisions that select between two exact code paths (the host build then follows the
+// per-environment predicate, so both paths are exercised by the CPU tests)
+#define XARM_ANY_X(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
 // Compiler-only fence.  The LDS columns are lane-private and never cross a barrier, so LLVM would
 // otherwise forward the staged values through registers (and then spill them to scratch).
 #define XARM_LDS_FENCE() asm volatile("" ::: "memory")
@@ -39,6 +42,7 @@
 #define XARM_HD inline
 // host build: always run the masked path so that the predication logic itself is tested
 #define XARM_ANY(p) (true)
+#define XARM_ANY_X(p) (p)
 #define XARM_LDS_FENCE() ((void)0)
 #endif
 

@@ -7,7 +7,7 @@
 //
 // Data placement: the arm part (arm_dynamics) is the PickAndPlace code and uses the same LDS columns; the object
 // contact data (12 table slots, 3 x 4 cube/cube points) lives in further lane-private LDS columns - this scene's
-// BASELINE size is 8192 envs per GPU = one wavefront per CU, so a wavefront may take ~108 KB of the CU's 160 KB.
+// BASELINE size is 8192 envs per GPU = one wavefront per CU, so a wavefront may take ~124 KB of the CU's 160 KB.
 // Both lanes of an env compute the object-only rows redundantly (bit-identical); the cube velocities are handed from
 // lane to lane between the two finger phases of a sweep exactly as the Handover scene hands over its stick.
 #pragma once
@@ -26,7 +26,8 @@ constexpr int TP_W = 11;                      // r3 lam3 vt invd3 id
 constexpr int LDS_TP = xk::LDS_TBL;           // 12 table slots
 constexpr int BB_W = 13, BB_PAIR = 6 + 4 * BB_W; // per pair: n3 t1_3, then 4 x (rA3 rB3 lam3 vt invd3)
 constexpr int LDS_BB = LDS_TP + NOBJ * 4 * TP_W;
-constexpr int LDS_FLOATS = LDS_BB + NPAIR * BB_PAIR;   // 423 floats = 1692 B per lane
+constexpr int LDS_CLIP = LDS_BB + NPAIR * BB_PAIR;     // 3 x 8 x 3 floats: polygon ping-pong + kept points of cube_cube
+constexpr int LDS_FLOATS = LDS_CLIP + 72;              // 495 floats = 1980 B per lane, 124 KB per wavefront
 
 struct StackScene {
     static constexpr int NARMS = 2;
@@ -55,77 +56,93 @@ template <typename T> struct Lane {
 
 template <typename T> XARM_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 template <typename T> XARM_HD V3<T> sel3v(int i, V3<T> a, V3<T> b, V3<T> c) { return mk<T>(sel3(i, a.x, b.x, c.x), sel3(i, a.y, b.y, c.y), sel3(i, a.z, b.z, c.z)); }
+// component-wise select (a conditional expression on two V3 lvalues selects an ADDRESS, which keeps both in memory)
+template <typename T> XARM_HD V3<T> selv(bool c, V3<T> a, V3<T> b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 template <typename T> XARM_HD V3<T> ldv(const T (&a)[3]) { return mk<T>(a[0], a[1], a[2]); }
 
 // ---- cube/cube manifold (same algorithm and tie-breaking as box_box in oracle/xarm_oracle_stack.inc.c).
 // A[k], B[k]: box axes in the world; both boxes are cubes of half edge h.  Returns the number of points (<= 4),
-// normal from B to A.
-template <typename T> struct CV { T x, y, z; };
-template <typename T> XARM_HD int clip_axis(const CV<T> *in, int n, CV<T> *out, int axis, T sgn, T h) {
+// normal from B to A.  Everything with a compile-time index stays in registers (all fixed loops are unrolled, the
+// run-time axis choices are selects); the clipped polygon, whose vertex count is data dependent, lives in the
+// lane's LDS columns [LDS_CLIP, LDS_CLIP + 72) - private (scratch) arrays cost ~2 us per dependent access here.
+template <typename T, typename Lds> XARM_HD int clip_axis(Lds lds, int in, int n, int out, int axis, T sgn, T h) {
     int m = 0;
     for (int i = 0; i < n; i++) {
-        const CV<T> a = in[i], b = in[i + 1 == n ? 0 : i + 1];
-        const T da = sgn * (axis == 0 ? a.x : a.y) - h, db = sgn * (axis == 0 ? b.x : b.y) - h;
-        if (da <= (T)0) out[m++] = a;
+        const int ia = in + 3 * i, ib = in + 3 * (i + 1 == n ? 0 : i + 1);
+        const T ax = lds[ia], ay = lds[ia + 1], az = lds[ia + 2], bx = lds[ib], by = lds[ib + 1], bz = lds[ib + 2];
+        const T da = sgn * (axis == 0 ? ax : ay) - h, db = sgn * (axis == 0 ? bx : by) - h;
+        if (da <= (T)0) { lds[out + 3 * m] = ax; lds[out + 3 * m + 1] = ay; lds[out + 3 * m + 2] = az; m++; }
         if ((da <= (T)0) != (db <= (T)0)) {
             const T t = da / (da - db);
-            CV<T> c;
-            c.x = a.x + t * (b.x - a.x); c.y = a.y + t * (b.y - a.y); c.z = a.z + t * (b.z - a.z);
-            out[m++] = c;
+            lds[out + 3 * m] = ax + t * (bx - ax); lds[out + 3 * m + 1] = ay + t * (by - ay); lds[out + 3 * m + 2] = az + t * (bz - az);
+            m++;
         }
     }
     return m;
 }
-template <typename T>
-XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[3], T h, T margin, V3<T> (&pts)[4], V3<T> &nrm, T (&dist)[4]) {
+template <typename T, typename Lds>
+XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[3], T h, T margin, V3<T> (&pts)[4], V3<T> &nrm, T (&dist)[4], Lds lds) {
     const V3<T> t = pB - pA;
     T tA[3], tB[3], C[3][3], Q[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++) { tA[i] = dot(A[i], t); tB[i] = dot(B[i], t); }
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) { C[i][j] = dot(A[i], B[j]); Q[i][j] = xk::xabs(C[i][j]); }
     T best = (T)-1e30;
     int code = -1;
+    bool sep = false;
+#pragma unroll
     for (int i = 0; i < 3; i++) {
         const T s = xk::xabs(tA[i]) - (h + h * Q[i][0] + h * Q[i][1] + h * Q[i][2]);
-        if (s > margin) return 0;
+        sep = sep || s > margin;
         if (s > best) { best = s; code = i; }
     }
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         const T s = xk::xabs(tB[j]) - (h + h * Q[0][j] + h * Q[1][j] + h * Q[2][j]);
-        if (s > margin) return 0;
+        sep = sep || s > margin;
         if (s > best) { best = s; code = 3 + j; }
     }
     T ebest = (T)-1e30;
-    V3<T> eaxis = mk<T>(0, 0, 0);
+    V3<T> eaxis = mk<T>(0, 0, 0), eA = mk<T>(0, 0, 0), eB = mk<T>(0, 0, 0);
     int ei = -1, ej = -1;
+    T euaub = (T)0;
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             const T l2 = (T)1 - C[i][j] * C[i][j];
-            if (l2 < (T)1e-6) continue;
             const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-            const T l = xk::xsqrt(l2);
+            const bool ok = !(l2 < (T)1e-6);
+            const T l = xk::xsqrt(ok ? l2 : (T)1);
             const T expr = tA[i2] * C[i1][j] - tA[i1] * C[i2][j];
             const T ra = h * Q[i2][j] + h * Q[i1][j], rb = h * Q[i][j2] + h * Q[i][j1];
             const T s = (xk::xabs(expr) - (ra + rb)) / l;
-            if (s > margin) return 0;
-            if (s > ebest) {
+            sep = sep || (ok && s > margin);
+            if (ok && s > ebest) {
                 ebest = s; ei = i; ej = j;
                 const V3<T> L = cross(A[i], B[j]);
                 const T sg = (expr < (T)0 ? (T)-1 : (T)1) / l;
-                eaxis = L * sg;
+                eaxis = L * sg; eA = A[i]; eB = B[j]; euaub = C[i][j];
             }
         }
+    // a separating axis anywhere means no contact (the oracle returns at the first one; the verdict is the same)
+    if (sep) return 0;
     if (ei >= 0 && ebest - (T)1e-5 - (T)0.05 * xk::xabs(ebest) > best) {
         V3<T> pa = pA, pb = pB;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
-            if (k != ei) pa = pa + A[k] * ((dot(eaxis, A[k]) >= (T)0 ? (T)1 : (T)-1) * h);
-            if (k != ej) pb = pb + B[k] * ((dot(eaxis, B[k]) >= (T)0 ? (T)-1 : (T)1) * h);
+            const V3<T> da = A[k] * ((dot(eaxis, A[k]) >= (T)0 ? (T)1 : (T)-1) * h), db = B[k] * ((dot(eaxis, B[k]) >= (T)0 ? (T)-1 : (T)1) * h);
+            pa = k != ei ? pa + da : pa;
+            pb = k != ej ? pb + db : pb;
         }
         const V3<T> p = pb - pa;
-        const T uaub = C[ei][ej], q1 = dot(A[ei], p), q2 = -dot(B[ej], p), dd = (T)1 - uaub * uaub;
-        const T alpha = (q1 + uaub * q2) / dd, beta = (uaub * q1 + q2) / dd;
-        pa = pa + A[ei] * alpha;
-        pb = pb + B[ej] * beta;
+        const T q1 = dot(eA, p), q2 = -dot(eB, p), dd = (T)1 - euaub * euaub;
+        const T alpha = (q1 + euaub * q2) / dd, beta = (euaub * q1 + q2) / dd;
+        pa = pa + eA * alpha;
+        pb = pb + eB * beta;
         pts[0] = (pa + pb) * (T)0.5;
         nrm = eaxis * (T)-1;
         dist[0] = ebest;
@@ -134,66 +151,76 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
     const bool refA = code < 3;
     const int ri = refA ? code : code - 3;
     V3<T> Rx[3], Ix[3];
-    for (int k = 0; k < 3; k++) { Rx[k] = refA ? A[k] : B[k]; Ix[k] = refA ? B[k] : A[k]; }
-    const V3<T> pR = refA ? pA : pB, pI = refA ? pB : pA;
-    const T sgR = refA ? (tA[ri] < (T)0 ? (T)-1 : (T)1) : (tB[ri] > (T)0 ? (T)-1 : (T)1);
-    const V3<T> dR = Rx[ri] * sgR;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Rx[k] = selv(refA, A[k], B[k]); Ix[k] = selv(refA, B[k], A[k]); }
+    const V3<T> pR = selv(refA, pA, pB), pI = selv(refA, pB, pA);
+    const T tAr = sel3(ri, tA[0], tA[1], tA[2]), tBr = sel3(ri, tB[0], tB[1], tB[2]);
+    const T sgR = refA ? (tAr < (T)0 ? (T)-1 : (T)1) : (tBr > (T)0 ? (T)-1 : (T)1);
+    const V3<T> Rri = sel3v(ri, Rx[0], Rx[1], Rx[2]);
+    const V3<T> dR = Rri * sgR;
     int jj = 0;
     T bestdot = (T)-1;
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         const T d = xk::xabs(dot(Ix[j], dR));
         if (d > bestdot) { bestdot = d; jj = j; }
     }
-    const T sj = dot(Ix[jj], dR) > (T)0 ? (T)-1 : (T)1;
-    const int j1 = (jj + 1) % 3, j2 = (jj + 2) % 3, r1 = (ri + 1) % 3, r2 = (ri + 2) % 3;
-    CV<T> poly[2][8];
+    const V3<T> Ijj = sel3v(jj, Ix[0], Ix[1], Ix[2]), Ij1 = sel3v(jj, Ix[1], Ix[2], Ix[0]), Ij2 = sel3v(jj, Ix[2], Ix[0], Ix[1]);
+    const V3<T> Rr1 = sel3v(ri, Rx[1], Rx[2], Rx[0]), Rr2 = sel3v(ri, Rx[2], Rx[0], Rx[1]);
+    const T sj = dot(Ijj, dR) > (T)0 ? (T)-1 : (T)1;
+    constexpr int P0 = LDS_CLIP, P1 = LDS_CLIP + 24, KP = LDS_CLIP + 48;
     int n = 4;
+#pragma unroll
     for (int v = 0; v < 4; v++) {
         const T su = (v == 0 || v == 3) ? (T)1 : (T)-1, sv = v < 2 ? (T)1 : (T)-1;
-        const V3<T> w = pI + Ix[jj] * (sj * h) + Ix[j1] * (su * h) + Ix[j2] * (sv * h) - pR;
-        poly[0][v].x = dot(w, Rx[r1]);
-        poly[0][v].y = dot(w, Rx[r2]);
-        poly[0][v].z = dot(w, dR) - h;
+        const V3<T> w = pI + Ijj * (sj * h) + Ij1 * (su * h) + Ij2 * (sv * h) - pR;
+        lds[P0 + 3 * v] = dot(w, Rr1);
+        lds[P0 + 3 * v + 1] = dot(w, Rr2);
+        lds[P0 + 3 * v + 2] = dot(w, dR) - h;
     }
-    n = clip_axis<T>(poly[0], n, poly[1], 0, (T)1, h);
-    n = clip_axis<T>(poly[1], n, poly[0], 0, (T)-1, h);
-    n = clip_axis<T>(poly[0], n, poly[1], 1, (T)1, h);
-    n = clip_axis<T>(poly[1], n, poly[0], 1, (T)-1, h);
-    CV<T> keep[8];
+    n = clip_axis<T, Lds>(lds, P0, n, P1, 0, (T)1, h);
+    n = clip_axis<T, Lds>(lds, P1, n, P0, 0, (T)-1, h);
+    n = clip_axis<T, Lds>(lds, P0, n, P1, 1, (T)1, h);
+    n = clip_axis<T, Lds>(lds, P1, n, P0, 1, (T)-1, h);
     int nk = 0;
     for (int i = 0; i < n; i++)
-        if (poly[0][i].z < margin) keep[nk++] = poly[0][i];
-    if (nk == 0) return 0;
-    int sel[4], ns = 0;
-    if (nk <= 4) {
-        for (int i = 0; i < nk; i++) sel[ns++] = i;
-    } else {
-        T cx = (T)0, cy = (T)0;
-        int i0 = 0;
-        for (int i = 0; i < nk; i++) { cx += keep[i].x; cy += keep[i].y; if (keep[i].z < keep[i0].z) i0 = i; }
-        cx /= (T)nk; cy /= (T)nk;
-        const T a0 = xk::xatan2(keep[i0].y - cy, keep[i0].x - cx);
-        bool used[8] = {false, false, false, false, false, false, false, false};
-        used[i0] = true;
-        sel[ns++] = i0;
-        for (int q = 1; q < 4; q++) {
-            const T want = a0 + (T)q * (T)1.5707963267948966;
-            int bi = -1;
-            T bd = (T)1e30;
-            for (int i = 0; i < nk; i++) {
-                if (used[i]) continue;
-                const T a = xk::xatan2(keep[i].y - cy, keep[i].x - cx);
-                const T d = xk::xabs(xk::xremainder(a - want, (T)6.283185307179586));
-                if (d < bd) { bd = d; bi = i; }
-            }
-            used[bi] = true;
-            sel[ns++] = bi;
+        if (lds[P0 + 3 * i + 2] < margin) {
+            lds[KP + 3 * nk] = lds[P0 + 3 * i]; lds[KP + 3 * nk + 1] = lds[P0 + 3 * i + 1]; lds[KP + 3 * nk + 2] = lds[P0 + 3 * i + 2];
+            nk++;
         }
+    if (nk == 0) return 0;
+    int s0 = 0, s1 = 1, s2 = 2, s3 = 3, ns = nk;
+    if (nk > 4) {
+        // the deepest point, the one farthest from it, and the farthest one on either side of that line
+        int i0 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 1; i < nk; i++) if (lds[KP + 3 * i + 2] < lds[KP + 3 * i0 + 2]) i0 = i;
+        const T x0 = lds[KP + 3 * i0], y0 = lds[KP + 3 * i0 + 1];
+        T best1 = (T)-1;
+        for (int i = 0; i < nk; i++) {
+            if (i == i0) continue;
+            const T dx = lds[KP + 3 * i] - x0, dy = lds[KP + 3 * i + 1] - y0, d2 = dx * dx + dy * dy;
+            if (d2 > best1) { best1 = d2; i1 = i; }
+        }
+        const T ex = lds[KP + 3 * i1] - x0, ey = lds[KP + 3 * i1 + 1] - y0;
+        T smax = (T)0, smin = (T)0;
+        for (int i = 0; i < nk; i++) {
+            if (i == i0 || i == i1) continue;
+            const T sd = ex * (lds[KP + 3 * i + 1] - y0) - ey * (lds[KP + 3 * i] - x0);
+            if (sd > smax) { smax = sd; i2 = i; }
+            if (sd < smin) { smin = sd; i3 = i; }
+        }
+        s0 = i0; s1 = i1; ns = 2;
+        if (i2 >= 0) { s2 = i2; ns = 3; }
+        if (i3 >= 0) { if (ns == 2) s2 = i3; else s3 = i3; ns++; }
     }
-    for (int q = 0; q < ns; q++) {
-        const CV<T> v = keep[sel[q]];
-        pts[q] = pR + Rx[r1] * v.x + Rx[r2] * v.y + dR * (v.z + h);
-        dist[q] = v.z;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int si = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+        if (q < ns) {
+            const T vx = lds[KP + 3 * si], vy = lds[KP + 3 * si + 1], vz = lds[KP + 3 * si + 2];
+            pts[q] = pR + Rr1 * vx + Rr2 * vy + dR * (vz + h);
+            dist[q] = vz;
+        }
     }
     nrm = refA ? dR * (T)-1 : dR;
     return ns;
@@ -279,7 +306,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
         if (XARM_ANY(near)) {
             V3<T> pts[4], nrm = mk<T>(0, 0, 1);
             T dist[4];
-            const int np = near ? cube_cube<T>(cb[a], Rb[a], cb[b], Rb[b], h, (T)xm::SOLVER_MARGIN, pts, nrm, dist) : 0;
+            const int np = near ? cube_cube<T, Lds>(cb[a], Rb[a], cb[b], Rb[b], h, (T)xm::SOLVER_MARGIN, pts, nrm, dist, lds) : 0;
             if (np > 0) {
                 bb_any = true;
                 const V3<T> t1 = xk::plane_space(nrm), t2 = cross(nrm, t1);
@@ -469,6 +496,12 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             wb[o] = mk<T>(xchg.from0(wb[o].x), xchg.from0(wb[o].y), xchg.from0(wb[o].z));
         }
     }
+    // cubes touched by this arm's active pads / by the partner arm's; `seq` is wave-uniform
+    int mymask = 0;
+#pragma unroll
+    for (int idx = 0; idx < NP; idx++) mymask |= pp[idx].invd[0] != (T)0 ? (1 << pc[idx]) : 0;
+    const int othermask = (int)xchg.partner((T)mymask);
+    const bool seq = XARM_ANY_X((mymask & othermask) != 0);
     XARM_LDS_FENCE();
 
     // ---------------- projected Gauss-Seidel: T, BB, (M L G) of this lane's arm, F arm 0, F arm 1
@@ -589,10 +622,14 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
             for (int r = 0; r < 9; r++) dq[r] += (Minv[symi(r, 7)] - Minv[symi(r, 8)]) * dl;
         }
-        // (F) pad points of arm 0, hand the cube velocities over, pad points of arm 1
+        // (F) pad points.  Sequential form: arm 0's pads, hand the cube velocities over, arm 1's pads.  When no cube
+        // of any environment in the wavefront is touched by both arms the two sweeps act on disjoint variables and
+        // commute, so both lanes sweep at once (phase 0) and each cube is then taken from the lane that touched it.
+        // One instruction stream serves both forms (a second copy of the sweep pushes the cube velocities to scratch).
 #pragma unroll
         for (int ph = 0; ph < 2; ph++) {
-            const bool mine = arm == ph;
+            // sequential: phase 0 = arm 0, phase 1 = arm 1; concurrent: every lane sweeps in phase 0, phase 1 is empty
+            const bool mine = seq ? arm == ph : ph == 0;
             if (XARM_ANY(pad_any && mine)) {
                 T y[6], yf[2], wtot[8];
 #pragma unroll
@@ -674,11 +711,18 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
             for (int o = 0; o < NOBJ; o++) {
                 if (ph == 0) {
-                    vb[o] = mk<T>(xchg.from0(vb[o].x), xchg.from0(vb[o].y), xchg.from0(vb[o].z));
-                    wb[o] = mk<T>(xchg.from0(wb[o].x), xchg.from0(wb[o].y), xchg.from0(wb[o].z));
+                    const bool take = ((othermask >> o) & 1) != 0;   // concurrent: the partner lane touched cube o, this one did not
+                    const V3<T> f0 = mk<T>(xchg.from0(vb[o].x), xchg.from0(vb[o].y), xchg.from0(vb[o].z));
+                    const V3<T> g0 = mk<T>(xchg.from0(wb[o].x), xchg.from0(wb[o].y), xchg.from0(wb[o].z));
+                    const V3<T> pv = mk<T>(xchg.partner(vb[o].x), xchg.partner(vb[o].y), xchg.partner(vb[o].z));
+                    const V3<T> pw = mk<T>(xchg.partner(wb[o].x), xchg.partner(wb[o].y), xchg.partner(wb[o].z));
+                    vb[o] = selv(seq, f0, selv(take, pv, vb[o]));
+                    wb[o] = selv(seq, g0, selv(take, pw, wb[o]));
                 } else {
-                    vb[o] = mk<T>(xchg.from1(vb[o].x), xchg.from1(vb[o].y), xchg.from1(vb[o].z));
-                    wb[o] = mk<T>(xchg.from1(wb[o].x), xchg.from1(wb[o].y), xchg.from1(wb[o].z));
+                    const V3<T> f1 = mk<T>(xchg.from1(vb[o].x), xchg.from1(vb[o].y), xchg.from1(vb[o].z));
+                    const V3<T> g1 = mk<T>(xchg.from1(wb[o].x), xchg.from1(wb[o].y), xchg.from1(wb[o].z));
+                    vb[o] = selv(seq, f1, vb[o]);
+                    wb[o] = selv(seq, g1, wb[o]);
                 }
             }
         }

@@ -11,7 +11,7 @@
  * of Bullet's pipeline and is recorded in gym_xarm_amd/model/xarm7_pd.json["stack_tower"]["_contact_model"]:
  *   - cube corners against the table top, first 4 active corners per cube (as PickAndPlace);
  *   - cube/cube: 15-axis separating-axis test; a face axis gives the incident face clipped against the reference
- *     face (<= 4 points kept: the deepest, then the three closest to 90 degree steps around the centroid), an
+ *     face (<= 4 points kept: the deepest, the one farthest from it, the farthest on either side of that line), an
  *     edge/edge axis gives one point midway between the closest points of the two edges (the algorithm family of
  *     Bullet's btBoxBoxDetector); speculative points up to solver_margin, no warm start;
  *   - each pad sphere against its nearest cube only.
@@ -228,27 +228,27 @@ static int box_box(const real *pA, const real *RA, const real *hA, const real *p
     if (nk <= 4) {
         for (int i = 0; i < nk; i++) sel[ns++] = i;
     } else {
-        /* deepest point first, then the points closest to +90, +180, +270 degrees around the centroid */
-        real cx = 0, cy = 0;
-        int i0 = 0;
-        for (int i = 0; i < nk; i++) { cx += keep[i].x; cy += keep[i].y; if (keep[i].z < keep[i0].z) i0 = i; }
-        cx /= nk; cy /= nk;
-        real a0 = atan2(keep[i0].y - cy, keep[i0].x - cx);
-        int used[16] = {0};
-        used[i0] = 1;
-        sel[ns++] = i0;
-        for (int q = 1; q < 4; q++) {
-            real want = a0 + q * 1.5707963267948966;
-            int bi = -1;
-            real bd = 1e30;
-            for (int i = 0; i < nk; i++) {
-                if (used[i]) continue;
-                real a = atan2(keep[i].y - cy, keep[i].x - cx), d = fabs(remainder(a - want, 6.283185307179586));
-                if (d < bd) { bd = d; bi = i; }
-            }
-            used[bi] = 1;
-            sel[ns++] = bi;
+        /* 4 of the n > 4 points (the idea of btPersistentManifold::sortCachedPoints: keep the deepest point and a
+         * large area): the deepest, the one farthest from it, and the farthest one on either side of that line */
+        int i0 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 1; i < nk; i++) if (keep[i].z < keep[i0].z) i0 = i;
+        real best1 = -1;
+        for (int i = 0; i < nk; i++) {
+            if (i == i0) continue;
+            real dx = keep[i].x - keep[i0].x, dy = keep[i].y - keep[i0].y, d2 = dx * dx + dy * dy;
+            if (d2 > best1) { best1 = d2; i1 = i; }
         }
+        real ex = keep[i1].x - keep[i0].x, ey = keep[i1].y - keep[i0].y, smax = 0, smin = 0;
+        for (int i = 0; i < nk; i++) {
+            if (i == i0 || i == i1) continue;
+            real sd = ex * (keep[i].y - keep[i0].y) - ey * (keep[i].x - keep[i0].x);
+            if (sd > smax) { smax = sd; i2 = i; }
+            if (sd < smin) { smin = sd; i3 = i; }
+        }
+        sel[ns++] = i0;
+        sel[ns++] = i1;
+        if (i2 >= 0) sel[ns++] = i2;
+        if (i3 >= 0) sel[ns++] = i3;
     }
     for (int q = 0; q < ns; q++) {
         const cv_t *v = &keep[sel[q]];

@@ -335,15 +335,15 @@ void xh_st_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double 
 int xh_cube_cube(int f32, const double *pA, const double *RA, const double *pB, const double *RB, double h, double margin, double *pts, double *nrm, double *dist) {
     int n;
     if (f32) {
-        xk::V3<float> A[3], B[3], P[4], N; float D[4];
+        xk::V3<float> A[3], B[3], P[4], N; float D[4]; float lds[xs::LDS_FLOATS]; HostLds<float> hl{lds};
         for (int k = 0; k < 3; k++) { A[k] = xk::mk<float>((float)RA[k], (float)RA[3 + k], (float)RA[6 + k]); B[k] = xk::mk<float>((float)RB[k], (float)RB[3 + k], (float)RB[6 + k]); }
-        n = xs::cube_cube<float>(xk::mk<float>((float)pA[0], (float)pA[1], (float)pA[2]), A, xk::mk<float>((float)pB[0], (float)pB[1], (float)pB[2]), B, (float)h, (float)margin, P, N, D);
+        n = xs::cube_cube<float, HostLds<float>>(xk::mk<float>((float)pA[0], (float)pA[1], (float)pA[2]), A, xk::mk<float>((float)pB[0], (float)pB[1], (float)pB[2]), B, (float)h, (float)margin, P, N, D, hl);
         for (int q = 0; q < n; q++) { pts[3 * q] = P[q].x; pts[3 * q + 1] = P[q].y; pts[3 * q + 2] = P[q].z; dist[q] = D[q]; }
         if (n) { nrm[0] = N.x; nrm[1] = N.y; nrm[2] = N.z; }
     } else {
-        xk::V3<double> A[3], B[3], P[4], N; double D[4];
+        xk::V3<double> A[3], B[3], P[4], N; double D[4]; double lds[xs::LDS_FLOATS]; HostLds<double> hl{lds};
         for (int k = 0; k < 3; k++) { A[k] = xk::mk<double>(RA[k], RA[3 + k], RA[6 + k]); B[k] = xk::mk<double>(RB[k], RB[3 + k], RB[6 + k]); }
-        n = xs::cube_cube<double>(xk::mk<double>(pA[0], pA[1], pA[2]), A, xk::mk<double>(pB[0], pB[1], pB[2]), B, h, margin, P, N, D);
+        n = xs::cube_cube<double, HostLds<double>>(xk::mk<double>(pA[0], pA[1], pA[2]), A, xk::mk<double>(pB[0], pB[1], pB[2]), B, h, margin, P, N, D, hl);
         for (int q = 0; q < n; q++) { pts[3 * q] = P[q].x; pts[3 * q + 1] = P[q].y; pts[3 * q + 2] = P[q].z; dist[q] = D[q]; }
         if (n) { nrm[0] = N.x; nrm[1] = N.y; nrm[2] = N.z; }
     }

@@ -113,6 +113,37 @@ def test_stack_host_f64_contact_scenarios(oracle, host):
     assert abs(st[1, 56 + 6] - 0.125) < 2e-3          # the tower still stands
 
 
+def test_stack_host_f64_both_arms_on_one_cube(oracle, host):
+    """both grippers closed on the same cube: the finger phases of the two arms must be swept one after the other
+    with the cube velocity handed over in between (the sequential path); elsewhere they commute and run at once"""
+    q = np.array([-0.009068751632859924, -0.08153217279952825, 0.09299669711139864, 1.067692645248743,
+                  0.0004018824370178429, 1.1524205092196147, -0.0004991403332530034, 0.04, 0.04])
+    for _ in range(40):   # hand of arm 1 to the point midway between the bases; arm 2 (mirrored) then sits at the same point
+        q = oracle.ik(q, [0.6, 0.0, 0.2], 15)[:9]
+        q[7:] = 0.04
+    ora = oracle.OracleStackTower(2, seed=5)
+    s = ora.get_state()
+    s[:, 0:9] = q; s[:, 9:18] = q
+    s[:, 36:54] = s[:, 0:18]
+    ora.set_state(s)
+    obs = ora.step(np.zeros((2, 8)))[0]
+    assert np.abs(obs[:, 39:42] - obs[:, 47:50]).max() < 2e-3          # the two hands coincide
+    s = ora.get_state()
+    s[0, 54:57] = obs[0, 39:42] - [0, 0, 0.067]                          # env 0: the cube between both pairs of pads
+    s[1, 54:57] = [0.2, 0.1, 0.025]                                      # env 1: nothing to grasp
+    s[:, 75:93] = 0
+    ora.set_state(s)
+    st = ora.get_state()
+    act = np.zeros((2, 8))
+    act[:, 3] = act[:, 7] = -1
+    for _ in range(3):
+        st, *_ = host.st_step(st, act, f32=0, seed=5)
+        ora.step(act)
+        assert np.abs(st - ora.get_state()).max() < 1e-9
+    assert st[0, 126:130].max() > 0 and st[0, 130:134].max() > 0, "both arms must hold the cube"
+    assert st[1, 126:134].max() == 0
+
+
 def test_stack_host_f32_close_to_oracle(oracle, host):
     E = 4
     ora = oracle.OracleStackTower(E, seed=9)

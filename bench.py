@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/sec of XarmPDPickAndPlace-v0 (BASELINE.json `metric`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one env step of EVERY environment of the job (one xarm_step call per rank), including
@@ -10,6 +10,11 @@ the automatic resets of finished episodes.  Weak scaling: each rank owns `--envs
 rank*E .. (rank+1)*E-1, no data-path collective.  Inputs are synthetic: a ring of
 64 pre-generated uniform[-1,1] action tensors resident in HBM, so the timed region contains no RNG
 and no host->device traffic.  Rank 0 prints ONE JSON line.
+
+`--workload` selects one of the other BASELINE.json configs for the same measurement (same JSON schema, its own
+metric name): reach = config 2 (XarmReach-v0, 4 096 envs), stack = config 4 (XarmPDStackTower-v0, 8 192 envs per
+GPU), handover = config 5 (XarmPDHandover-v0, 16 384 envs per GPU).  The default (pnp, 65 536 envs per GPU) is the
+configuration BASELINE.json's `metric` is quoted on and the only one the driver runs.
 """
 import argparse
 import json
@@ -23,19 +28,39 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CU x 4 SIMD x 16 lanes x 2 pk x 2 fma x 2.4 GHz), the bound that binds
 ALGO_BYTES_PER_ENV_STEP = 452  # SURVEY.md 8(d), PnP N=1: state in+out, action in, obs/goals/reward/flags out
+# workload -> (env id, default envs per GPU, action width, SURVEY 8(d) algorithmic bytes per env step, step kernel,
+#              oracle class, CPU-baseline sample (envs per thread, steps), config dict)
+WORKLOADS = {
+    "pnp": ("XarmPDPickAndPlace-v0", 65536, 4, ALGO_BYTES_PER_ENV_STEP, "k_step", "OraclePnP", (128, 60),
+            dict(GUI=False, num_obj=1, reward_type="sparse", init_grasp_rate=0.0, goal_ground_rate=0.0, goal_shape="air")),
+    "reach": ("XarmReach-v0", 4096, 4, 336, "k_reach_step", "OracleReach", (256, 100), None),
+    "handover": ("XarmPDHandover-v0", 16384, 8, 648, "k_ho_step", "OracleHandover", (16, 30),
+                 dict(GUI=False, num_obj=1, same_side_rate=0.5, goal_shape="ground", use_stand=False)),
+    "stack": ("XarmPDStackTower-v0", 8192, 8, 1040, "k_st_step", "OracleStackTower", (64, 60), None),
+}
 
 
-def cpu_baseline(sample_envs_per_thread=128, steps=60):
+WORKLOAD_NAMES = {
+    "pnp": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",
+    "reach": "XarmReach-v0 (XarmReachEnv, sparse reward; BASELINE config 2)",
+    "handover": "XarmPDHandover-v0 (XarmHandover, num_obj=1, goal_shape=ground, same_side_rate=0.5; BASELINE config 5)",
+    "stack": "XarmPDStackTower-v0 (XarmStackTowerEnv, three cubes, sparse reward; BASELINE config 4)",
+}
+SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15}   # internal substeps (Handover: 15 ticks of one substep)
+
+
+def cpu_baseline(workload="pnp"):
     """The CPU oracle (a restatement = kind "port"; PyBullet itself is absent) on the host cores:
     every thread steps its own shard through ctypes (the GIL is released inside the C call)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.lib()
+    env_id, _, act_dim, _, _, cls, (sample_envs_per_thread, steps), _ = WORKLOADS[workload]
     cores = max(1, min(os.cpu_count() or 1, 16))
-    envs = [O.OraclePnP(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread) for k in range(cores)]
+    envs = [getattr(O, cls)(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread) for k in range(cores)]
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, size=(steps, cores, sample_envs_per_thread, 4))
+    acts = rng.uniform(-1, 1, size=(steps, cores, sample_envs_per_thread, act_dim))
 
     def work(k):
         envs[k].reset()
@@ -53,8 +78,8 @@ def cpu_baseline(sample_envs_per_thread=128, steps=60):
         wall_steps = time.perf_counter() - t0
     n = cores * sample_envs_per_thread * steps
     return {"value": n / wall_steps, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps of XarmPDPickAndPlace-v0 on the CPU oracle (float64, gcc -O2), %d threads, %.1f s"
-                      % (cores * sample_envs_per_thread, steps, cores, wall + wall_steps),
+            "sample": "%d envs x %d steps of %s on the CPU oracle (float64, gcc -O2), %d threads, %.1f s"
+                      % (cores * sample_envs_per_thread, steps, env_id, cores, wall + wall_steps),
             "reference": "unavailable (pybullet not importable)"}
 
 
@@ -63,7 +88,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pnp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,12 +116,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    E = args.envs_per_gpu
-    env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=0, env_id_offset=rank * E, device=dev,
-                            config=dict(GUI=False, num_obj=1, reward_type="sparse", init_grasp_rate=0.0,
-                                        goal_ground_rate=0.0, goal_shape="air"))
+    env_id, default_E, act_dim, algo_bytes_per_step, kernel_name, _, _, env_config = WORKLOADS[args.workload]
+    E = args.envs_per_gpu or default_E
+    env = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=rank * E, device=dev, config=env_config)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    ring = [torch.rand(E, 4, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
+    ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
     for i in range(args.warmup):
         env.step(ring[i % 64])
@@ -123,21 +148,21 @@ def main():
 
     if rank == 0:
         value = total_envs * args.steps / dt
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * E                 # one k_step launch processes E env steps
+        algo_bytes = algo_bytes_per_step * E                     # one step-kernel launch processes E env steps
         achieved = algo_bytes / (kstep_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_step_hbm_bytes_per_launch_%d" % E)
+                traffic = json.load(open(pmc)).get("%s_hbm_bytes_per_launch_%d" % (kernel_name, E))
             except Exception:
                 traffic = None
         # secondary ceiling (the one that actually binds): fp32 vector issue.  Wave-instruction count per launch
         # from the committed SQ_INSTS_VALU PMC pass, 64 lanes x 2 flop upper bound per instruction.
         valu = None
-        if traffic is not None:
+        if os.path.exists(pmc):
             try:
-                n_valu = json.load(open(pmc)).get("k_step_valu_wave_insts_per_launch_%d" % E)
+                n_valu = json.load(open(pmc)).get("%s_valu_wave_insts_per_launch_%d" % (kernel_name, E))
                 if n_valu:
                     tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
                     valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction)",
@@ -145,14 +170,14 @@ def main():
             except Exception:
                 valu = None
         out = {
-            "metric": "env steps/sec (whole node), XarmPDPickAndPlace-v0", "value": value, "unit": "env steps/s", "n_gpus": world,
+            "metric": "env steps/sec (whole node), %s" % env_id, "value": value, "unit": "env steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",
-                       "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": 15, "solver_iterations": 50,
+            "config": {"workload": WORKLOAD_NAMES[args.workload],
+                       "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": SUBSTEPS[args.workload], "solver_iterations": 50,
                        "auto_reset": True, "episodes_reset_in_window": int(resets), "parallelism": "env-shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_step",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                          "kernel_avg_ms": kstep_ms, "kernel_launches": int(launches),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "fused step: HBM is touched once per env step, the kernel is fp32-VALU/latency bound (DESIGN.md)"},
@@ -161,7 +186,7 @@ def main():
         if valu is not None:
             out["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

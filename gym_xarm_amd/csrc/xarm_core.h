@@ -76,6 +76,8 @@ template <typename T> XARM_HD V3<T> symmul(const T (&s)[6], V3<T> v) {
     return mk<T>(s[0] * v.x + s[1] * v.y + s[2] * v.z, s[1] * v.x + s[3] * v.y + s[4] * v.z,
                  s[2] * v.x + s[4] * v.y + s[5] * v.z);
 }
+// component-wise select (a conditional expression on two V3 lvalues selects an ADDRESS, which keeps both in memory)
+template <typename T> XARM_HD V3<T> selv(bool c, V3<T> a, V3<T> b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 template <typename T> XARM_HD T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 template <typename T> XARM_HD T comp(V3<T> v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
@@ -837,6 +839,12 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     }
     st.touch = (touch_f[0] && touch_f[1]) ? (T)1 : (T)0;
 
+    // two arms: the finger phases of the two arms commute unless both arms touch the object; `seq` is wave-uniform
+    bool other_any = false, seq = false;
+    if (Scene::NARMS == 2) {
+        other_any = xchg.partner(pad_any ? (T)1 : (T)0) != (T)0;
+        seq = XARM_ANY_X(pad_any && other_any);
+    }
     // ---------------- projected Gauss-Seidel, rows in the order T, M, L, G, F
     const T mu_p = (T)xm::MU_OBJECT * (st.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
 #pragma unroll 1
@@ -922,7 +930,8 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         // swept first, the object velocity is handed to the other lane, then the pads of arm 1
 #pragma unroll
         for (int ph = 0; ph < Scene::NARMS; ph++) {
-        const bool mine = Scene::NARMS == 1 || arm == ph;
+        // two arms: sequential (phase = arm) when both touch the object; otherwise the touching arm sweeps in phase 0
+        const bool mine = Scene::NARMS == 1 || (seq ? arm == ph : ph == 0);
         if (XARM_ANY(pad_any && mine)) {
             T y[6], yf[2], wtot[8];
 #pragma unroll
@@ -1013,11 +1022,15 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         }
         if (Scene::NARMS == 2) {
             if (ph == 0) {
-                vb = mk<T>(xchg.from0(vb.x), xchg.from0(vb.y), xchg.from0(vb.z));
-                wb = mk<T>(xchg.from0(wb.x), xchg.from0(wb.y), xchg.from0(wb.z));
+                const V3<T> f0 = mk<T>(xchg.from0(vb.x), xchg.from0(vb.y), xchg.from0(vb.z)), g0 = mk<T>(xchg.from0(wb.x), xchg.from0(wb.y), xchg.from0(wb.z));
+                const V3<T> pv = mk<T>(xchg.partner(vb.x), xchg.partner(vb.y), xchg.partner(vb.z)), pw = mk<T>(xchg.partner(wb.x), xchg.partner(wb.y), xchg.partner(wb.z));
+                // concurrent form: the object is taken from the lane whose pads touched it
+                vb = selv(seq, f0, selv(other_any, pv, vb));
+                wb = selv(seq, g0, selv(other_any, pw, wb));
             } else {
-                vb = mk<T>(xchg.from1(vb.x), xchg.from1(vb.y), xchg.from1(vb.z));
-                wb = mk<T>(xchg.from1(wb.x), xchg.from1(wb.y), xchg.from1(wb.z));
+                const V3<T> f1 = mk<T>(xchg.from1(vb.x), xchg.from1(vb.y), xchg.from1(vb.z)), g1 = mk<T>(xchg.from1(wb.x), xchg.from1(wb.y), xchg.from1(wb.z));
+                vb = selv(seq, f1, vb);
+                wb = selv(seq, g1, wb);
             }
         }
         }

@@ -56,8 +56,7 @@ template <typename T> struct Lane {
 
 template <typename T> XARM_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 template <typename T> XARM_HD V3<T> sel3v(int i, V3<T> a, V3<T> b, V3<T> c) { return mk<T>(sel3(i, a.x, b.x, c.x), sel3(i, a.y, b.y, c.y), sel3(i, a.z, b.z, c.z)); }
-// component-wise select (a conditional expression on two V3 lvalues selects an ADDRESS, which keeps both in memory)
-template <typename T> XARM_HD V3<T> selv(bool c, V3<T> a, V3<T> b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+using xk::selv;
 template <typename T> XARM_HD V3<T> ldv(const T (&a)[3]) { return mk<T>(a[0], a[1], a[2]); }
 
 // ---- cube/cube manifold (same algorithm and tie-breaking as box_box in oracle/xarm_oracle_stack.inc.c).

@@ -581,12 +581,24 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     }
     V3<T> vb = mk<T>(st.bv[0], st.bv[1], st.bv[2]), wb = mk<T>(st.bw[0], st.bw[1], st.bw[2]);
     {
-        // gyroscopic torque in body axes, gravity, Bullet's (1 - damping)^dt damping
-        V3<T> wl = mk<T>(dot(b0, wb), dot(b1, wb), dot(b2, wb));
-        V3<T> Iw = mk<T>(Ibx * wl.x, Iby * wl.y, Ibz * wl.z);
-        V3<T> g = cross(Iw, wl);
-        V3<T> gw = b0 * g.x + b1 * g.y + b2 * g.z;
-        wb = wb + symmul(Iinv, gw) * dt;
+        // gyroscopic term as btRigidBody::computeGyroscopicImpulseImplicit_Body (Bullet's default): one Newton step of
+        // I (w' - w) + dt w' x (I w') = 0 in body axes, J = I + dt ([w]x I - [I w]x), w' = w - J^-1 (dt w x I w).
+        // (the explicit form gains energy every step and runs away once |w| dt ~ 1); then gravity and damping
+        {
+            const V3<T> wl = mk<T>(dot(b0, wb), dot(b1, wb), dot(b2, wb));
+            const V3<T> iw = mk<T>(Ibx * wl.x, Iby * wl.y, Ibz * wl.z);
+            const V3<T> f = cross(wl, iw) * dt;
+            const T J00 = Ibx, J01 = dt * (-wl.z * Iby + iw.z), J02 = dt * (wl.y * Ibz - iw.y);
+            const T J10 = dt * (wl.z * Ibx - iw.z), J11 = Iby, J12 = dt * (-wl.x * Ibz + iw.x);
+            const T J20 = dt * (-wl.y * Ibx + iw.y), J21 = dt * (wl.x * Iby - iw.x), J22 = Ibz;
+            const T c00 = J11 * J22 - J12 * J21, c01 = J12 * J20 - J10 * J22, c02 = J10 * J21 - J11 * J20;
+            const T id = (T)1 / (J00 * c00 + J01 * c01 + J02 * c02);
+            const V3<T> x = mk<T>((f.x * c00 + f.y * (J02 * J21 - J01 * J22) + f.z * (J01 * J12 - J02 * J11)) * id,
+                                  (f.x * c01 + f.y * (J00 * J22 - J02 * J20) + f.z * (J02 * J10 - J00 * J12)) * id,
+                                  (f.x * c02 + f.y * (J01 * J20 - J00 * J21) + f.z * (J00 * J11 - J01 * J10)) * id);
+            const V3<T> wn = wl - x;
+            wb = b0 * wn.x + b1 * wn.y + b2 * wn.z;
+        }
         vb.z -= dt * (T)xm::GRAVITY;
         // Bullet's pow(1 - damping, dt); dt is always timeStep / numSubSteps, folded by the header generator
         const T dl = (T)Scene::LIN_DAMP_FACTOR, da = (T)Scene::ANG_DAMP_FACTOR;

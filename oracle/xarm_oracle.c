@@ -604,6 +604,32 @@ static int sphere_box(const real *c, real rho, const real *cb, const real *Rb, c
     return *dist < margin;
 }
 
+/* btRigidBody::computeGyroscopicImpulseImplicit_Body (Bullet's default for rigid bodies,
+ * BT_ENABLE_GYROSCOPIC_FORCE_IMPLICIT_BODY): one Newton step of the implicit Euler equation
+ *     I (w' - w) + dt * w' x (I w') = 0
+ * in body axes, f = dt * w x (I w), J = I + dt * ([w]x I - [I w]x), w' = w - J^-1 f (Cramer, as solve33).
+ * The explicit form w += dt * I^-1 ((I w) x w) gains energy every step and runs away once |w| dt ~ 1 (a box
+ * knocked into a spin by the gripper reached 1e6 rad/s within an episode). */
+static void gyro_implicit(const real *Rb, const real *Ib, real dt, real *w /* world, in/out */) {
+    real wl[3], iw[3], f[3], J[9], x[3], wn[3];
+    m3_tvec(wl, Rb, w);
+    v3_set(iw, Ib[0] * wl[0], Ib[1] * wl[1], Ib[2] * wl[2]);
+    v3_cross(f, wl, iw);
+    for (int k = 0; k < 3; k++) f[k] *= dt;
+    const real s0[9] = {0, -wl[2], wl[1], wl[2], 0, -wl[0], -wl[1], wl[0], 0};
+    const real s1[9] = {0, -iw[2], iw[1], iw[2], 0, -iw[0], -iw[1], iw[0], 0};
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) J[r * 3 + c] = (r == c ? Ib[r] : 0.0) + dt * (s0[r * 3 + c] * Ib[c] - s1[r * 3 + c]);
+    real c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    real det = J[0] * c00 + J[1] * c01 + J[2] * c02, id = 1.0 / det;
+    x[0] = (f[0] * c00 + f[1] * (J[2] * J[7] - J[1] * J[8]) + f[2] * (J[1] * J[5] - J[2] * J[4])) * id;
+    x[1] = (f[0] * c01 + f[1] * (J[0] * J[8] - J[2] * J[6]) + f[2] * (J[2] * J[3] - J[0] * J[5])) * id;
+    x[2] = (f[0] * c02 + f[1] * (J[1] * J[6] - J[0] * J[7]) + f[2] * (J[0] * J[4] - J[1] * J[3])) * id;
+    for (int k = 0; k < 3; k++) wl[k] -= x[k];
+    m3_vec(wn, Rb, wl);
+    v3_copy(w, wn);
+}
+
 /* ------------------------------------------------------------------ one internal substep
  * (btMultiBodyDynamicsWorld::internalSingleStepSimulation, dt = timeStep / numSubSteps) */
 static void substep(const xo_model *m, real *st, const real *q_target, real dt) {
@@ -635,14 +661,8 @@ static void substep(const xo_model *m, real *st, const real *q_target, real dt) 
     aba_forward_dynamics(m, &s.t, qd, tau, m->gravity, qdd);
     for (int k = 0; k < nd; k++) qd[k] += dt * qdd[k];
     {
-        /* gyroscopic torque, gravity, then Bullet's (1-damping)^dt velocity damping */
-        real wl[3], Iw[3], g[3], gw[3], dw[3];
-        m3_tvec(wl, s.Rb, vb + 3);
-        v3_set(Iw, Ib[0] * wl[0], Ib[1] * wl[1], Ib[2] * wl[2]);
-        v3_cross(g, Iw, wl); /* -(w x Iw) in body axes */
-        m3_vec(gw, s.Rb, g);
-        m3_vec(dw, s.Iinv_w, gw);
-        v3_axpy(vb + 3, dt, dw);
+        /* gyroscopic term (implicit, body axes), gravity, then Bullet's (1-damping)^dt velocity damping */
+        gyro_implicit(s.Rb, Ib, dt, vb + 3);
         vb[2] -= dt * m->gravity;
         real dl = pow(1.0 - m->lin_damping, dt), da = pow(1.0 - m->ang_damping, dt);
         for (int k = 0; k < 3; k++) { vb[k] *= dl; vb[k + 3] *= da; }
@@ -1207,13 +1227,7 @@ static void ho_substep(const xo_model *m, const xo_ho_cfg *c, real *st, const re
         for (int k = 0; k < 9; k++) qd[k] += dt * qdd[k];
     }
     {
-        real wl[3], Iw[3], g[3], gw[3], dw[3];
-        m3_tvec(wl, s.Rb, vb + 3);
-        v3_set(Iw, Ib[0] * wl[0], Ib[1] * wl[1], Ib[2] * wl[2]);
-        v3_cross(g, Iw, wl);
-        m3_vec(gw, s.Rb, g);
-        m3_vec(dw, s.Iinv_w, gw);
-        v3_axpy(vb + 3, dt, dw);
+        gyro_implicit(s.Rb, Ib, dt, vb + 3);
         vb[2] -= dt * m->gravity;
         real dl = pow(1.0 - m->lin_damping, dt), da = pow(1.0 - m->ang_damping, dt);
         for (int k = 0; k < 3; k++) { vb[k] *= dl; vb[k + 3] *= da; }

@@ -38,8 +38,8 @@ def test_oracle_handover_behaviour(oracle, groll):
     S = groll["states"]
     both = (S[:, :, 70:72].sum(axis=2) == 2).any(axis=0)
     assert both.sum() >= 5                                            # both grippers hold the stick at some step
-    crossed = (S[30][:, 38] * S[0][:, 38] < 0) & (S[30][:, 40] > 0.03)
-    assert crossed.sum() >= 2                                         # ... and it ends on the other arm's side, lifted
+    crossed = ((S[:, :, 38] * S[0][None, :, 38] < 0) & (S[:, :, 40] > 0.03)).any(axis=0)
+    assert crossed.sum() >= 2                                         # ... and it is carried, lifted, to the other arm's side
     js = oracle.load_model_json()["handover"]
     env = oracle.OracleHandover(256, seed=4, same_side_rate=1.0, goal_shape="ground")
     env.reset()

@@ -1,0 +1,51 @@
+"""Robustness: long rollouts under hostile actions stay finite and bounded.  (A box knocked into a fast spin used
+to gain energy through the explicitly integrated gyroscopic term until its angular velocity overflowed; Bullet's
+default - and now this build's - is the implicit body-frame update, btRigidBody::computeGyroscopicImpulseImplicit_Body.)"""
+import numpy as np
+import pytest
+
+
+def test_oracle_free_spin_does_not_gain_energy(oracle):
+    env = oracle.OraclePnP(2, seed=0)
+    s = env.get_state()
+    s[:, 18:21] = [0.4, 0.0, 5.0]                      # high above the table: free flight for the whole test
+    s[:, 25:28] = 0
+    s[0, 28:31] = [300.0, 20.0, 150.0]
+    s[1, 28:31] = [5.0, 900.0, -40.0]
+    env.set_state(s)
+    w0 = np.linalg.norm(s[:, 28:31], axis=1)
+    prev = w0.copy()
+    for _ in range(12):
+        env.step(np.zeros((2, 4)))
+        w = np.linalg.norm(env.get_state()[:, 28:31], axis=1)
+        assert np.all(w <= prev * (1 + 1e-9)), (w, prev)
+        prev = w
+    assert np.all(prev > 0.3 * w0)                      # damped, not killed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,E,A,steps,cfg", [
+    ("XarmPDPickAndPlace-v0", 4096, 4, 160, None),
+    ("XarmPDPickAndPlace-v0", 2048, 4, 100, dict(init_grasp_rate=1.0, reward_type="dense", goal_shape="ground")),
+    ("XarmReach-v0", 4096, 4, 60, None),
+    ("XarmPDHandover-v0", 2048, 8, 120, None),
+    ("XarmPDStackTower-v0", 2048, 8, 110, None),
+])
+def test_long_hostile_rollouts_stay_finite(env_id, E, A, steps, cfg):
+    import torch
+    import gym_xarm_amd
+    env = gym_xarm_amd.make(env_id, num_envs=E, seed=7, config=cfg)
+    env.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(3)
+    worst = 0.0
+    for k in range(steps):
+        a = torch.rand(E, A, device=env.device, generator=g) * 2.4 - 1.2      # beyond the clip range on purpose
+        if k % 7 == 0:
+            a = torch.sign(a)                                                 # saturated actions
+        obs, rew, done, info = env.step(a)
+        assert bool(torch.isfinite(obs["observation"]).all()) and bool(torch.isfinite(rew).all()), "step %d" % k
+        worst = max(worst, float(obs["observation"].abs().max()))
+    assert bool(torch.isfinite(env.get_state()).all())
+    assert worst < 5e3, worst      # velocities of knocked-about objects reach a few hundred rad/s, not 1e6
+    env.close()

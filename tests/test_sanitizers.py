@@ -20,6 +20,9 @@ void xh_step(int, uint64_t, int64_t, double, double, int, int, int64_t, double*,
 void xh_reach_init(int, uint64_t, int64_t, int, int64_t, double*);
 void xh_reach_reset(int, uint64_t, int64_t, int, int64_t, double*, const uint8_t*, double*, double*, double*);
 void xh_reach_step(int, uint64_t, int64_t, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*, int32_t*);
+void xh_st_init(int, uint64_t, int64_t, int, int64_t, double*);
+void xh_st_reset(int, uint64_t, int64_t, int, int64_t, double*, const uint8_t*, double*, double*, double*);
+void xh_st_step(int, uint64_t, int64_t, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*);
 }
 int main() {
     const int64_t E = 6;
@@ -39,6 +42,19 @@ int main() {
         xh_reach_reset(f32, 1, 0, 2, E, rs, 0, ro, ag, dg);
         for (int t = 0; t < 3; t++) xh_reach_step(f32, 1, 0, 2, E, rs, act, ro, ag, dg, rew, done, succ, fut);
         free(rs); free(ro);
+        // StackTower: two lanes (threads) per env; env 0 gets two overlapping cubes so that the cube/cube manifold
+        // (clipped polygon in the lane's LDS columns) and its solver rows run under the sanitizers too
+        const int64_t ES = 2;
+        double *ss = (double*)calloc(ES * 136, 8), *so = (double*)calloc(ES * 55, 8), *sg = (double*)calloc(ES * 9, 8), *sd = (double*)calloc(ES * 9, 8);
+        double *sa = (double*)calloc(ES * 8, 8);
+        xh_st_init(f32, 5, 0, 0, ES, ss);
+        xh_st_reset(f32, 5, 0, 0, ES, ss, 0, so, sg, sd);
+        ss[57] = ss[54] + 0.03; ss[58] = ss[55] + 0.004; ss[59] = ss[56];
+        for (int t = 0; t < 2; t++) {
+            for (int k = 0; k < ES * 8; k++) sa[k] = ((t * 5 + k * 11) % 21) / 10.0 - 1.0;
+            xh_st_step(f32, 5, 0, 0, ES, ss, sa, so, sg, sd, rew, done, succ);
+        }
+        free(ss); free(so); free(sg); free(sd); free(sa);
     }
     printf("ok %f\n", st[0] + obs[0]);
     free(st); free(obs); free(ag); free(dg); free(rew); free(act); free(done); free(succ); free(fut);
@@ -64,7 +80,8 @@ def test_kernel_core_under_asan_ubsan(tmp_path):
     main = tmp_path / "main.cpp"
     main.write_text(MAIN)
     exe = tmp_path / "san_core"
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    # -g1: line tables only (full debug info of the fully inlined templates triples the compile time)
+    subprocess.check_call(["g++", "-O1", "-g1", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-Wno-unknown-pragmas", "-o", str(exe), str(main), os.path.join(ROOT, "tests", "hostbuild", "xarm_host.cpp")])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))

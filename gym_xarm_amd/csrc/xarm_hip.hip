@@ -419,7 +419,7 @@ __global__ void k_ho_compute_reward(const float *__restrict__ ag, const float *_
 }
 
 // --------------------------------------------------------------------- XarmPDStackTower-v0 (two lanes per env)
-// 495 LDS floats per lane = 124 KB per wavefront: one wavefront per CU, which is this scene's BASELINE size
+// 603 LDS floats per lane = 151 KB per wavefront: one wavefront per CU, which is this scene's BASELINE size
 // (8192 envs per GPU = 256 wavefronts)
 __device__ __forceinline__ void st_load(const KParams &P, int64_t e, int arm, xs::Lane<float> &L) {
     const float *S = P.state + e;

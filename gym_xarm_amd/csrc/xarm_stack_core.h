@@ -7,7 +7,7 @@
 //
 // Data placement: the arm part (arm_dynamics) is the PickAndPlace code and uses the same LDS columns; the object
 // contact data (12 table slots, 3 x 4 cube/cube points) lives in further lane-private LDS columns - this scene's
-// BASELINE size is 8192 envs per GPU = one wavefront per CU, so a wavefront may take ~124 KB of the CU's 160 KB.
+// BASELINE size is 8192 envs per GPU = one wavefront per CU, so a wavefront may take ~151 KB of the CU's 160 KB.
 // Both lanes of an env compute the object-only rows redundantly (bit-identical); the cube velocities are handed from
 // lane to lane between the two finger phases of a sweep exactly as the Handover scene hands over its stick.
 #pragma once
@@ -24,10 +24,10 @@ enum { K_Q = 0, K_QD = 18, K_QT = 36, K_BP = 54, K_BQ = 63, K_BV = 75, K_BW = 84
 // extra LDS columns behind the arm's S | T | A_hh (the arm's table-slot columns are reused)
 constexpr int TP_W = 11;                      // r3 lam3 vt invd3 id
 constexpr int LDS_TP = xk::LDS_TBL;           // 12 table slots
-constexpr int BB_W = 13, BB_PAIR = 6 + 4 * BB_W; // per pair: n3 t1_3, then 4 x (rA3 rB3 lam3 vt invd3)
+constexpr int BB_W = 22, BB_PAIR = 6 + 4 * BB_W; // per pair: n3 t1_3, then 4 x (rA3 rB3 lam3 vt invd3 Kn3 Kt1_3 Kt2_3)
 constexpr int LDS_BB = LDS_TP + NOBJ * 4 * TP_W;
 constexpr int LDS_CLIP = LDS_BB + NPAIR * BB_PAIR;     // 3 x 8 x 3 floats: polygon ping-pong + kept points of cube_cube
-constexpr int LDS_FLOATS = LDS_CLIP + 72;              // 495 floats = 1980 B per lane, 124 KB per wavefront
+constexpr int LDS_FLOATS = LDS_CLIP + 72;              // 603 floats = 2412 B per lane, 151 KB per wavefront
 
 struct StackScene {
     static constexpr int NARMS = 2;
@@ -318,10 +318,15 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                     lds[pb + 0] = rA.x; lds[pb + 1] = rA.y; lds[pb + 2] = rA.z;
                     lds[pb + 3] = rB.x; lds[pb + 4] = rB.y; lds[pb + 5] = rB.z;
                     lds[pb + 9] = dist[q] < (T)0 ? -(T)xm::CONTACT_ERP * dist[q] * idt : -dist[q] * idt;
-                    const T an = dot(rA, nrm), bn = dot(rB, nrm), a1 = dot(rA, t1), b1 = dot(rB, t1), a2 = dot(rA, t2), b2 = dot(rB, t2);
-                    lds[pb + 10] = (T)1 / ((T)2 * imb + ii * (ra2 - an * an) + ii * (rb2 - bn * bn));
-                    lds[pb + 11] = (T)1 / ((T)2 * imb + ii * (ra2 - a1 * a1) + ii * (rb2 - b1 * b1));
-                    lds[pb + 12] = (T)1 / ((T)2 * imb + ii * (ra2 - a2 * a2) + ii * (rb2 - b2 * b2));
+                    // point Delassus block K = (2/m + (|rA|^2 + |rB|^2)/I) 1 - (rA rA^T + rB rB^T)/I; K d for the three rows
+                    const T kd = (T)2 * imb + ii * (ra2 + rb2);
+                    const V3<T> dirs[3] = {nrm, t1, t2};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const V3<T> Kd = dirs[k] * kd - (rA * dot(rA, dirs[k]) + rB * dot(rB, dirs[k])) * ii;
+                        lds[pb + 10 + k] = (T)1 / dot(dirs[k], Kd);
+                        lds[pb + 13 + 3 * k] = Kd.x; lds[pb + 14 + 3 * k] = Kd.y; lds[pb + 15 + 3 * k] = Kd.z;
+                    }
                 }
             }
         }
@@ -558,19 +563,23 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                     T lam[3] = {lds[pb + 6], lds[pb + 7], lds[pb + 8]};
                     const T ed[3] = {e0, lds[pb + 11], lds[pb + 12]};
                     const T vt = lds[pb + 9];
+                    // relative velocity at the point once, then kept current through K d per row; one impulse at the end
+                    V3<T> u = vb[a] + cross(wb[a], rA) - vb[b] - cross(wb[b], rB);
+                    V3<T> f = mk<T>(0, 0, 0);
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const V3<T> d = k == 0 ? n : (k == 1 ? t1 : t2);
-                        const V3<T> u = vb[a] + cross(wb[a], rA) - vb[b] - cross(wb[b], rB);
+                        const V3<T> Kd = mk<T>(lds[pb + 13 + 3 * k], lds[pb + 14 + 3 * k], lds[pb + 15 + 3 * k]);
                         T dl = ((k == 0 ? vt : (T)0) - dot(d, u)) * ed[k];
                         const T lim = mu_bb * lam[0];
                         const T nl = k == 0 ? (lam[0] + dl < (T)0 ? (T)0 : lam[0] + dl) : clampT(lam[k] + dl, -lim, lim);
                         dl = nl - lam[k];
                         lam[k] = nl;
-                        const V3<T> f = d * dl;
-                        vb[a] = vb[a] + f * imb; wb[a] = wb[a] + cross(rA, f) * ii;
-                        vb[b] = vb[b] - f * imb; wb[b] = wb[b] - cross(rB, f) * ii;
+                        u = u + Kd * dl;
+                        f = f + d * dl;
                     }
+                    vb[a] = vb[a] + f * imb; wb[a] = wb[a] + cross(rA, f) * ii;
+                    vb[b] = vb[b] - f * imb; wb[b] = wb[b] - cross(rB, f) * ii;
                     lds[pb + 6] = lam[0]; lds[pb + 7] = lam[1]; lds[pb + 8] = lam[2];
                 }
             }

@@ -78,6 +78,28 @@ template <typename T> XARM_HD V3<T> symmul(const T (&s)[6], V3<T> v) {
 }
 // component-wise select (a conditional expression on two V3 lvalues selects an ADDRESS, which keeps both in memory)
 template <typename T> XARM_HD V3<T> selv(bool c, V3<T> a, V3<T> b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+// two values that are always updated together (pairs of joint velocities / of Minv column entries): on the device
+// a float pair is an aligned VGPR pair and `pkfma` one v_pk_fma_f32 with the scalar broadcast by op_sel - a lone
+// wavefront issues a packed fma at the rate of a scalar one (tools/probes/lane_probe.hip), so this halves the
+// instruction count of the column updates.  Host / double: two scalars.
+template <typename T> struct Pk { T a, b; };
+template <typename T> XARM_HD T pklo(const Pk<T> &p) { return p.a; }
+template <typename T> XARM_HD T pkhi(const Pk<T> &p) { return p.b; }
+template <typename T> XARM_HD Pk<T> mkpk(T a, T b) { Pk<T> r; r.a = a; r.b = b; return r; }
+template <typename T> XARM_HD Pk<T> pkfma(const Pk<T> &m, T s, const Pk<T> &c) { Pk<T> r; r.a = m.a * s + c.a; r.b = m.b * s + c.b; return r; }
+#if defined(__HIPCC__) && !defined(XARM_HOST_BUILD)
+typedef float xf2 __attribute__((ext_vector_type(2)));
+template <> struct Pk<float> { xf2 v; };
+XARM_HD float pklo(const Pk<float> &p) { return p.v.x; }
+XARM_HD float pkhi(const Pk<float> &p) { return p.v.y; }
+template <> XARM_HD Pk<float> mkpk<float>(float a, float b) { Pk<float> r; r.v.x = a; r.v.y = b; return r; }
+XARM_HD Pk<float> pkfma(const Pk<float> &m, float s, const Pk<float> &c) {
+    Pk<float> r;
+    xf2 sp; sp.x = s; sp.y = s;
+    r.v = __builtin_elementwise_fma(m.v, sp, c.v);
+    return r;
+}
+#endif
 template <typename T> XARM_HD T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 template <typename T> XARM_HD T comp(V3<T> v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
@@ -857,6 +879,19 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         other_any = xchg.partner(pad_any ? (T)1 : (T)0) != (T)0;
         seq = XARM_ANY_X(pad_any && other_any);
     }
+    // packed working set of the sweep: joint velocities as 4 pairs + dq[8], full columns of Minv as pairs
+    Pk<T> dqp[4], MC[9][4];
+    T dq8 = dq[8], ML[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) dqp[k] = mkpk<T>(dq[2 * k], dq[2 * k + 1]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) MC[i][k] = mkpk<T>(Minv[symi(2 * k, i)], Minv[symi(2 * k + 1, i)]);
+        ML[i] = Minv[symi(8, i)];
+    }
+#define XARM_DQ(i) ((i) == 8 ? dq8 : (((i) & 1) ? pkhi(dqp[(i) >> 1]) : pklo(dqp[(i) >> 1])))
+#define XARM_DQ_AXPY(col, dl_) do { _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dqp[k_] = pkfma(MC[col][k_], (dl_), dqp[k_]); dq8 += ML[col] * (dl_); } while (0)
     // ---------------- projected Gauss-Seidel, rows in the order T, M, L, G, F
     const T mu_p = (T)xm::MU_OBJECT * (st.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
 #pragma unroll 1
@@ -896,47 +931,44 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const T hi = i < 7 ? m_hi_arm : m_hi_fin;
-            T dl = (m_vt[i] - dq[i]) * m_invd[i];
+            T dl = (m_vt[i] - XARM_DQ(i)) * m_invd[i];
             const T nl = clampT(m_lam[i] + dl, -hi, hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XARM_DQ_AXPY(i, dl);
         }
         // (L) joint limits: arm (one side at most), then fingers (lower, upper)
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             if (!XARM_ANY(la_sg[i] != (T)0)) continue;
             const T sg = la_sg[i];
-            T dl = (la_vt[i] - sg * dq[i]) * (sg != (T)0 ? m_invd[i] : (T)0);
+            T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;
             nl = nl < (T)0 ? (T)0 : nl;
             dl = (nl - la_lam[i]) * sg;
             la_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XARM_DQ_AXPY(i, dl);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++)
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const T sg = side == 0 ? (T)1 : (T)-1;
-                T dl = (lf_vt[k][side] - sg * dq[7 + k]) * m_invd[7 + k];
+                T dl = (lf_vt[k][side] - sg * XARM_DQ(7 + k)) * m_invd[7 + k];
                 T nl = lf_lam[k][side] + dl;
                 nl = nl < (T)0 ? (T)0 : nl;
                 dl = (nl - lf_lam[k][side]) * sg;
                 lf_lam[k][side] = nl;
-#pragma unroll
-                for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, 7 + k)] * dl;
+                XARM_DQ_AXPY(7 + k, dl);
             }
         // (G) gear row, q7' - q8' = 0
         {
-            T dl = (g_vt - (dq[7] - dq[8])) * g_invd;
+            T dl = (g_vt - (XARM_DQ(7) - dq8)) * g_invd;
             const T nl = clampT(g_lam + dl, -g_hi, g_hi);
             dl = nl - g_lam;
             g_lam = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += (Minv[symi(r, 7)] - Minv[symi(r, 8)]) * dl;
+            XARM_DQ_AXPY(7, dl);
+            XARM_DQ_AXPY(8, -dl);
         }
         // (F) pad points, each solved as a 3x3 block in operational space; with two arms the pads of arm 0 are
         // swept first, the object velocity is handed to the other lane, then the pads of arm 1
@@ -950,10 +982,10 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             for (int k = 0; k < 6; k++) {
                 T s = (T)0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) s += lds[LDS_S + i * 6 + k] * dq[i];
+                for (int i = 0; i < 7; i++) s += lds[LDS_S + i * 6 + k] * XARM_DQ(i);
                 y[k] = s;
             }
-            yf[0] = dq[7]; yf[1] = dq[8];
+            yf[0] = XARM_DQ(7); yf[1] = dq8;
 #pragma unroll
             for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
@@ -1024,12 +1056,14 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 vb = vb - fsum * imb;
                 wb = wb - symmul(Iinv, bsum);
             }
+            XARM_DQ_AXPY(7, wtot[6]);
+            XARM_DQ_AXPY(8, wtot[7]);
 #pragma unroll
-            for (int r = 0; r < 9; r++) {
-                T s = Minv[symi(r, 7)] * wtot[6] + Minv[symi(r, 8)] * wtot[7];
+            for (int k = 0; k < 6; k++) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
-                dq[r] += s;
+                for (int r2 = 0; r2 < 4; r2++)
+                    dqp[r2] = pkfma(mkpk<T>(lds[LDS_T + (2 * r2) * 6 + k], lds[LDS_T + (2 * r2 + 1) * 6 + k]), wtot[k], dqp[r2]);
+                dq8 += lds[LDS_T + 8 * 6 + k] * wtot[k];
             }
         }
         if (Scene::NARMS == 2) {
@@ -1047,6 +1081,12 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         }
         }
     }
+
+#pragma unroll
+    for (int k = 0; k < 4; k++) { dq[2 * k] = pklo(dqp[k]); dq[2 * k + 1] = pkhi(dqp[k]); }
+    dq[8] = dq8;
+#undef XARM_DQ
+#undef XARM_DQ_AXPY
 
     // ---------------- store warm-start impulses, integrate (semi-implicit Euler)
 #pragma unroll

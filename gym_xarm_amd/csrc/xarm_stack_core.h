@@ -508,6 +508,19 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     const bool seq = XARM_ANY_X((mymask & othermask) != 0);
     XARM_LDS_FENCE();
 
+    // packed working set of the sweep (as PickAndPlace): joint velocities as 4 pairs + dq[8], full Minv columns as pairs
+    xk::Pk<T> dqp[4], MC[9][4];
+    T dq8 = dq[8], ML[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) dqp[k] = xk::mkpk<T>(dq[2 * k], dq[2 * k + 1]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) MC[i][k] = xk::mkpk<T>(Minv[symi(2 * k, i)], Minv[symi(2 * k + 1, i)]);
+        ML[i] = Minv[symi(8, i)];
+    }
+#define XARM_DQ(i) ((i) == 8 ? dq8 : (((i) & 1) ? xk::pkhi(dqp[(i) >> 1]) : xk::pklo(dqp[(i) >> 1])))
+#define XARM_DQ_AXPY(col, dl_) do { _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dqp[k_] = xk::pkfma(MC[col][k_], (dl_), dqp[k_]); dq8 += ML[col] * (dl_); } while (0)
     // ---------------- projected Gauss-Seidel: T, BB, (M L G) of this lane's arm, F arm 0, F arm 1
     const T mu_p = (T)(xm::MU_OBJECT * xm::MU_FINGER);
 #pragma unroll 1
@@ -588,47 +601,44 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const T hi = i < 7 ? m_hi_arm : m_hi_fin;
-            T dl = (m_vt[i] - dq[i]) * m_invd[i];
+            T dl = (m_vt[i] - XARM_DQ(i)) * m_invd[i];
             const T nl = clampT(m_lam[i] + dl, -hi, hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XARM_DQ_AXPY(i, dl);
         }
         // (L) joint limits
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             if (!XARM_ANY(la_sg[i] != (T)0)) continue;
             const T sg = la_sg[i];
-            T dl = (la_vt[i] - sg * dq[i]) * (sg != (T)0 ? m_invd[i] : (T)0);
+            T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;
             nl = nl < (T)0 ? (T)0 : nl;
             dl = (nl - la_lam[i]) * sg;
             la_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XARM_DQ_AXPY(i, dl);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++)
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const T sg = side == 0 ? (T)1 : (T)-1;
-                T dl = (lf_vt[k][side] - sg * dq[7 + k]) * m_invd[7 + k];
+                T dl = (lf_vt[k][side] - sg * XARM_DQ(7 + k)) * m_invd[7 + k];
                 T nl = lf_lam[k][side] + dl;
                 nl = nl < (T)0 ? (T)0 : nl;
                 dl = (nl - lf_lam[k][side]) * sg;
                 lf_lam[k][side] = nl;
-#pragma unroll
-                for (int r = 0; r < 9; r++) dq[r] += Minv[symi(r, 7 + k)] * dl;
+                XARM_DQ_AXPY(7 + k, dl);
             }
         // (G) gear row
         {
-            T dl = (g_vt - (dq[7] - dq[8])) * g_invd;
+            T dl = (g_vt - (XARM_DQ(7) - dq8)) * g_invd;
             const T nl = clampT(g_lam + dl, -g_hi, g_hi);
             dl = nl - g_lam;
             g_lam = nl;
-#pragma unroll
-            for (int r = 0; r < 9; r++) dq[r] += (Minv[symi(r, 7)] - Minv[symi(r, 8)]) * dl;
+            XARM_DQ_AXPY(7, dl);
+            XARM_DQ_AXPY(8, -dl);
         }
         // (F) pad points.  Sequential form: arm 0's pads, hand the cube velocities over, arm 1's pads.  When no cube
         // of any environment in the wavefront is touched by both arms the two sweeps act on disjoint variables and
@@ -644,10 +654,10 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                 for (int k = 0; k < 6; k++) {
                     T s = (T)0;
 #pragma unroll
-                    for (int i = 0; i < 7; i++) s += lds[LDS_S + i * 6 + k] * dq[i];
+                    for (int i = 0; i < 7; i++) s += lds[LDS_S + i * 6 + k] * XARM_DQ(i);
                     y[k] = s;
                 }
-                yf[0] = dq[7]; yf[1] = dq[8];
+                yf[0] = XARM_DQ(7); yf[1] = dq8;
 #pragma unroll
                 for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
@@ -708,12 +718,14 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                         wb[o] = co == o ? wb[o] - dw : wb[o];
                     }
                 }
+                XARM_DQ_AXPY(7, wtot[6]);
+                XARM_DQ_AXPY(8, wtot[7]);
 #pragma unroll
-                for (int r = 0; r < 9; r++) {
-                    T s = Minv[symi(r, 7)] * wtot[6] + Minv[symi(r, 8)] * wtot[7];
+                for (int k = 0; k < 6; k++) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
-                    dq[r] += s;
+                    for (int r2 = 0; r2 < 4; r2++)
+                        dqp[r2] = xk::pkfma(xk::mkpk<T>(lds[LDS_T + (2 * r2) * 6 + k], lds[LDS_T + (2 * r2 + 1) * 6 + k]), wtot[k], dqp[r2]);
+                    dq8 += lds[LDS_T + 8 * 6 + k] * wtot[k];
                 }
             }
 #pragma unroll
@@ -735,6 +747,11 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { dq[2 * k] = xk::pklo(dqp[k]); dq[2 * k + 1] = xk::pkhi(dqp[k]); }
+    dq[8] = dq8;
+#undef XARM_DQ
+#undef XARM_DQ_AXPY
     XARM_LDS_FENCE();
 
     // ---------------- store warm-start impulses, integrate (semi-implicit Euler)

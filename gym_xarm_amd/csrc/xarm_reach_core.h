@@ -232,30 +232,47 @@ template <typename T> XARM_HD void substep(EnvState<T> &st, const T dt) {
         l_vt[i] = g < (T)0 ? -(T)xm::GLOBAL_ERP * g * idt : -g * idt;
         l_lam[i] = (T)0;
     }
+    // packed working set (xk::Pk, as the PickAndPlace sweep): 13 joint velocities = 6 pairs + 1, Minv columns as pairs
+    static_assert(ND == 13, "pair layout below is for 13 dofs");
+    xk::Pk<T> dqp[6], MC[ND][6];
+    T dql = dq[12], ML[ND];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dqp[k] = xk::mkpk<T>(dq[2 * k], dq[2 * k + 1]);
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) MC[i][k] = xk::mkpk<T>(Minv[symi(2 * k, i)], Minv[symi(2 * k + 1, i)]);
+        ML[i] = Minv[symi(12, i)];
+    }
+#define XR_DQ(i) ((i) == 12 ? dql : (((i) & 1) ? xk::pkhi(dqp[(i) >> 1]) : xk::pklo(dqp[(i) >> 1])))
+#define XR_DQ_AXPY(col, dl_) do { _Pragma("unroll") for (int k_ = 0; k_ < 6; k_++) dqp[k_] = xk::pkfma(MC[col][k_], (dl_), dqp[k_]); dql += ML[col] * (dl_); } while (0)
 #pragma unroll 1
     for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
 #pragma unroll
         for (int i = 0; i < ND; i++) {
-            T dl = (m_vt[i] - dq[i]) * m_invd[i];
+            T dl = (m_vt[i] - XR_DQ(i)) * m_invd[i];
             const T nl = clampT(m_lam[i] + dl, -m_hi, m_hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < ND; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XR_DQ_AXPY(i, dl);
         }
 #pragma unroll
         for (int i = 0; i < ND; i++) {
             if (!XARM_ANY(l_sg[i] != (T)0)) continue;
             const T sg = l_sg[i];
-            T dl = (l_vt[i] - sg * dq[i]) * (sg != (T)0 ? m_invd[i] : (T)0);
+            T dl = (l_vt[i] - sg * XR_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = l_lam[i] + dl;
             nl = nl < (T)0 ? (T)0 : nl;
             dl = (nl - l_lam[i]) * sg;
             l_lam[i] = nl;
-#pragma unroll
-            for (int r = 0; r < ND; r++) dq[r] += Minv[symi(r, i)] * dl;
+            XR_DQ_AXPY(i, dl);
         }
     }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dq[2 * k] = xk::pklo(dqp[k]); dq[2 * k + 1] = xk::pkhi(dqp[k]); }
+    dq[12] = dql;
+#undef XR_DQ
+#undef XR_DQ_AXPY
 #pragma unroll
     for (int i = 0; i < ND; i++) { st.qd[i] = dq[i]; st.q[i] += dt * dq[i]; }
 }

@@ -12,7 +12,11 @@ SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h
 # -fno-slp-vectorize: LLVM's SLP pass pairs the scalar fp32 ops of the unrolled solver into v_pk_* instructions,
 # which need even-aligned register pairs; in this 400-live-value kernel that costs ~30 % extra v_mov and pushes
 # 1.3 KB/lane into scratch.  Without it the step kernel needs 28 B/lane of scratch and 18 % fewer instructions.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
+# -amdgpu-sched-strategy=iterative-ilp: the kernels run one wavefront per SIMD, so nothing hides the latency between
+# dependent instructions except the order of the wavefront's own instruction stream; the ILP-driven scheduler takes
+# the contact-path tick from 2.47 to 2.32 ms (tools/variant_time.sh; disabling post-RA scheduling costs +33 %).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
+               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def find_hipcc():

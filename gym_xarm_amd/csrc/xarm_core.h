@@ -901,7 +901,8 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
         for (int s = 0; s < NTS; s++) {
             TablePoint<T> &P = tp[s];
-            if (!XARM_ANY(P.id >= 0)) continue;
+            // no wave-level skip: the slot math is a no-op for inactive lanes (1/diag = 0) and, being independent of the
+            // motor rows that follow, fills their dependency stalls when both sit in one basic block
             const T Kxy = lds[LDS_TBL + s * 8 + 0], Kxz = lds[LDS_TBL + s * 8 + 1], Kyy = lds[LDS_TBL + s * 8 + 2],
                     Kyz = lds[LDS_TBL + s * 8 + 3], Kzz = lds[LDS_TBL + s * 8 + 4];
             V3<T> u = vb + cross(wb, P.r);

@@ -531,9 +531,10 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
         for (int o = 0; o < NOBJ; o++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
+                // no wave-level skip (1/diag = 0 makes an empty slot a no-op): the slots of different cubes and the arm
+                // rows are independent chains, and in one basic block they fill each other's dependency stalls
                 const int base = LDS_TP + (o * 4 + s) * TP_W;
                 const T e0 = lds[base + 7];
-                if (!XARM_ANY(e0 != (T)0)) continue;
                 const V3<T> r = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]);
                 const T e1 = lds[base + 8], e2 = lds[base + 9];
                 T l0 = lds[base + 3], l1 = lds[base + 4], l2 = lds[base + 5];

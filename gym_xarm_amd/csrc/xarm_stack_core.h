@@ -291,7 +291,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 
     // ---------------- (BB) cube / cube manifolds -> LDS
     const T mu_bb = (T)(xm::MU_OBJECT * xm::MU_OBJECT);
-    bool bb_any = false;
+    bool bb_any = false, pair_act[NPAIR] = {false, false, false};
 #pragma unroll
     for (int pr = 0; pr < NPAIR; pr++) {
         const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
@@ -307,7 +307,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             T dist[4];
             const int np = near ? cube_cube<T, Lds>(cb[a], Rb[a], cb[b], Rb[b], h, (T)xm::SOLVER_MARGIN, pts, nrm, dist, lds) : 0;
             if (np > 0) {
-                bb_any = true;
+                bb_any = true; pair_act[pr] = true;
                 const V3<T> t1 = xk::plane_space(nrm), t2 = cross(nrm, t1);
                 lds[base + 0] = nrm.x; lds[base + 1] = nrm.y; lds[base + 2] = nrm.z;
                 lds[base + 3] = t1.x; lds[base + 4] = t1.y; lds[base + 5] = t1.z;
@@ -565,14 +565,15 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             for (int pr = 0; pr < NPAIR; pr++) {
                 const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
                 const int base = LDS_BB + pr * BB_PAIR;
-                if (!XARM_ANY(lds[base + 6 + 10] != (T)0)) continue;
+                if (!XARM_ANY(pair_act[pr])) continue;
                 const V3<T> n = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]), t1 = mk<T>(lds[base + 3], lds[base + 4], lds[base + 5]);
                 const V3<T> t2 = cross(n, t1);
-#pragma unroll 1
+                // all four slots of an active pair, unrolled and unconditional (an empty slot is a no-op): the LDS reads
+                // of the next point are issued while the current one is solved
+#pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int pb = base + 6 + q * BB_W;
                     const T e0 = lds[pb + 10];
-                    if (!XARM_ANY(e0 != (T)0)) continue;
                     const V3<T> rA = mk<T>(lds[pb + 0], lds[pb + 1], lds[pb + 2]), rB = mk<T>(lds[pb + 3], lds[pb + 4], lds[pb + 5]);
                     T lam[3] = {lds[pb + 6], lds[pb + 7], lds[pb + 8]};
                     const T ed[3] = {e0, lds[pb + 11], lds[pb + 12]};

@@ -879,6 +879,11 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         other_any = xchg.partner(pad_any ? (T)1 : (T)0) != (T)0;
         seq = XARM_ANY_X(pad_any && other_any);
     }
+    // does any lane of the wavefront have an arm joint inside its limit window? (rare; one test instead of seven per sweep)
+    bool la_lane = false;
+#pragma unroll
+    for (int i = 0; i < 7; i++) la_lane = la_lane || la_sg[i] != (T)0;
+    const bool la_wave = XARM_ANY(la_lane);
     // packed working set of the sweep: joint velocities as 4 pairs + dq[8], full columns of Minv as pairs
     Pk<T> dqp[4], MC[9][4];
     T dq8 = dq[8], ML[9];
@@ -941,7 +946,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         // (L) joint limits: arm (one side at most), then fingers (lower, upper)
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            if (!XARM_ANY(la_sg[i] != (T)0)) continue;
+            if (!la_wave) continue;   // one wave-uniform test for all seven rows (decided once per substep)
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;

@@ -508,6 +508,10 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     const bool seq = XARM_ANY_X((mymask & othermask) != 0);
     XARM_LDS_FENCE();
 
+    bool la_lane = false;
+#pragma unroll
+    for (int i = 0; i < 7; i++) la_lane = la_lane || la_sg[i] != (T)0;
+    const bool la_wave = XARM_ANY(la_lane);
     // packed working set of the sweep (as PickAndPlace): joint velocities as 4 pairs + dq[8], full Minv columns as pairs
     xk::Pk<T> dqp[4], MC[9][4];
     T dq8 = dq[8], ML[9];
@@ -612,7 +616,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
         // (L) joint limits
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            if (!XARM_ANY(la_sg[i] != (T)0)) continue;
+            if (!la_wave) continue;   // one wave-uniform test for all seven rows (decided once per substep)
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;

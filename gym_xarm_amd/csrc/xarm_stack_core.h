@@ -563,46 +563,8 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                 vb[o] = v; wb[o] = w;
                 lds[base + 3] = l0; lds[base + 4] = l1; lds[base + 5] = l2;
             }
-        // (BB) cube / cube points
-        if (XARM_ANY(bb_any)) {
-#pragma unroll
-            for (int pr = 0; pr < NPAIR; pr++) {
-                const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
-                const int base = LDS_BB + pr * BB_PAIR;
-                if (!XARM_ANY(pair_act[pr])) continue;
-                const V3<T> n = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]), t1 = mk<T>(lds[base + 3], lds[base + 4], lds[base + 5]);
-                const V3<T> t2 = cross(n, t1);
-                // all four slots of an active pair, unrolled and unconditional (an empty slot is a no-op): the LDS reads
-                // of the next point are issued while the current one is solved
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int pb = base + 6 + q * BB_W;
-                    const T e0 = lds[pb + 10];
-                    const V3<T> rA = mk<T>(lds[pb + 0], lds[pb + 1], lds[pb + 2]), rB = mk<T>(lds[pb + 3], lds[pb + 4], lds[pb + 5]);
-                    T lam[3] = {lds[pb + 6], lds[pb + 7], lds[pb + 8]};
-                    const T ed[3] = {e0, lds[pb + 11], lds[pb + 12]};
-                    const T vt = lds[pb + 9];
-                    // relative velocity at the point once, then kept current through K d per row; one impulse at the end
-                    V3<T> u = vb[a] + cross(wb[a], rA) - vb[b] - cross(wb[b], rB);
-                    V3<T> f = mk<T>(0, 0, 0);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const V3<T> d = k == 0 ? n : (k == 1 ? t1 : t2);
-                        const V3<T> Kd = mk<T>(lds[pb + 13 + 3 * k], lds[pb + 14 + 3 * k], lds[pb + 15 + 3 * k]);
-                        T dl = ((k == 0 ? vt : (T)0) - dot(d, u)) * ed[k];
-                        const T lim = mu_bb * lam[0];
-                        const T nl = k == 0 ? (lam[0] + dl < (T)0 ? (T)0 : lam[0] + dl) : clampT(lam[k] + dl, -lim, lim);
-                        dl = nl - lam[k];
-                        lam[k] = nl;
-                        u = u + Kd * dl;
-                        f = f + d * dl;
-                    }
-                    vb[a] = vb[a] + f * imb; wb[a] = wb[a] + cross(rA, f) * ii;
-                    vb[b] = vb[b] - f * imb; wb[b] = wb[b] - cross(rB, f) * ii;
-                    lds[pb + 6] = lam[0]; lds[pb + 7] = lam[1]; lds[pb + 8] = lam[2];
-                }
-            }
-        }
+        // the arm rows (M L G) only touch this lane's joints and the T / BB rows only the cubes: issued next to the table
+        // slots (one basic block) they fill each other's dependency stalls; the result is the oracle's T, BB, MLG order
         // (M) velocity-level PD motors
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -645,6 +607,46 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             g_lam = nl;
             XARM_DQ_AXPY(7, dl);
             XARM_DQ_AXPY(8, -dl);
+        }
+        // (BB) cube / cube points
+        if (XARM_ANY(bb_any)) {
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; pr++) {
+                const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
+                const int base = LDS_BB + pr * BB_PAIR;
+                if (!XARM_ANY(pair_act[pr])) continue;
+                const V3<T> n = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]), t1 = mk<T>(lds[base + 3], lds[base + 4], lds[base + 5]);
+                const V3<T> t2 = cross(n, t1);
+                // all four slots of an active pair, unrolled and unconditional (an empty slot is a no-op): the LDS reads
+                // of the next point are issued while the current one is solved
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int pb = base + 6 + q * BB_W;
+                    const T e0 = lds[pb + 10];
+                    const V3<T> rA = mk<T>(lds[pb + 0], lds[pb + 1], lds[pb + 2]), rB = mk<T>(lds[pb + 3], lds[pb + 4], lds[pb + 5]);
+                    T lam[3] = {lds[pb + 6], lds[pb + 7], lds[pb + 8]};
+                    const T ed[3] = {e0, lds[pb + 11], lds[pb + 12]};
+                    const T vt = lds[pb + 9];
+                    // relative velocity at the point once, then kept current through K d per row; one impulse at the end
+                    V3<T> u = vb[a] + cross(wb[a], rA) - vb[b] - cross(wb[b], rB);
+                    V3<T> f = mk<T>(0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const V3<T> d = k == 0 ? n : (k == 1 ? t1 : t2);
+                        const V3<T> Kd = mk<T>(lds[pb + 13 + 3 * k], lds[pb + 14 + 3 * k], lds[pb + 15 + 3 * k]);
+                        T dl = ((k == 0 ? vt : (T)0) - dot(d, u)) * ed[k];
+                        const T lim = mu_bb * lam[0];
+                        const T nl = k == 0 ? (lam[0] + dl < (T)0 ? (T)0 : lam[0] + dl) : clampT(lam[k] + dl, -lim, lim);
+                        dl = nl - lam[k];
+                        lam[k] = nl;
+                        u = u + Kd * dl;
+                        f = f + d * dl;
+                    }
+                    vb[a] = vb[a] + f * imb; wb[a] = wb[a] + cross(rA, f) * ii;
+                    vb[b] = vb[b] - f * imb; wb[b] = wb[b] - cross(rB, f) * ii;
+                    lds[pb + 6] = lam[0]; lds[pb + 7] = lam[1]; lds[pb + 8] = lam[2];
+                }
+            }
         }
         // (F) pad points.  Sequential form: arm 0's pads, hand the cube velocities over, arm 1's pads.  When no cube
         // of any environment in the wavefront is touched by both arms the two sweeps act on disjoint variables and

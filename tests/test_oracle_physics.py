@@ -78,3 +78,36 @@ def test_arm_holds_its_pose_against_gravity(oracle):
     st = env.get_state()[0]
     assert np.abs(oracle.fk(st[:9])[0][7] - hand0).max() < 1e-3
     assert np.abs(st[9:16]).max() < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ the HIP path itself
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_hip_path_free_fall_and_coulomb_sliding():
+    """the same closed forms on the device (float32): not only 'equal to the oracle' but equal to the analytic answers"""
+    import torch
+    import gym_xarm_amd
+    env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=64, seed=0, auto_reset=False)
+    env.reset()
+    s = env.get_state()
+    s[:, 34:50] = 0
+    s[:, 21:25] = torch.tensor([0., 0., 0., 1.], device=env.device)
+    s[:, 28:31] = 0
+    s[:32, 18:21] = torch.tensor([0.8, 0.0, 3.0], device=env.device); s[:32, 25:28] = 0              # free fall beside the table
+    s[32:, 18:21] = torch.tensor([0.1, 0.0, 0.04], device=env.device)                                 # sliding on the table
+    s[32:, 25:28] = torch.tensor([0.6, 0.0, 0.0], device=env.device)
+    env.set_state(s)
+    z, v, damp = 3.0, 0.0, (1.0 - 0.04) ** DT_SUB
+    for _ in range(12):
+        env.step(torch.zeros(64, 4))
+        for _ in range(N_SUB):
+            v = (v - G * DT_SUB) * damp
+            z += DT_SUB * v
+    st = env.get_state().cpu().numpy()
+    assert np.abs(st[:32, 20] - z).max() < 2e-5 and np.abs(st[:32, 27] - v).max() < 2e-5
+    assert np.abs(st[32:, 25]).max() < 1e-3                                                            # stopped
+    assert np.abs((st[32:, 18] - 0.1) - 0.6 ** 2 / (2 * 0.5 * G)).max() < 3e-3                         # after 36.7 mm
+    assert np.abs(st[32:, 20] - 0.04).max() < 3e-4
+    env.close()

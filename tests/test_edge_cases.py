@@ -1,0 +1,58 @@
+"""Edge cases at the boundary on the GPU: empty / partial reset masks, zero-length reward batches, invalid arguments,
+env counts that are not multiples of the wavefront, and independence of an env from the batch it runs in."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENVS = [("XarmPDPickAndPlace-v0", 4), ("XarmReach-v0", 4), ("XarmPDHandover-v0", 8), ("XarmPDStackTower-v0", 8)]
+
+
+@pytest.mark.parametrize("env_id,A", ENVS)
+def test_masks_empty_batches_and_bad_arguments(env_id, A):
+    import torch
+    import gym_xarm_amd
+    from gym_xarm_amd._native import XarmNativeError
+    E = 37                                                       # not a multiple of 32 / 64
+    env = gym_xarm_amd.make(env_id, num_envs=E, seed=2, auto_reset=False)
+    env.reset()
+    before = env.get_state().clone()
+    env.reset(mask=torch.zeros(E, dtype=torch.uint8))            # empty mask: nothing changes
+    assert torch.equal(env.get_state(), before)
+    m = torch.zeros(E, dtype=torch.uint8)
+    m[[0, 5, 36]] = 1
+    for _ in range(2):
+        env.step(torch.zeros(E, A))
+    mid = env.get_state().clone()
+    env.reset(mask=m)                                            # ragged mask: only those rows change
+    after = env.get_state()
+    changed = (after != mid).any(dim=1).cpu().numpy()
+    assert changed[[0, 5, 36]].all() and not changed[np.setdiff1d(np.arange(E), [0, 5, 36])].any()
+    g = env.goal_dim
+    assert env.compute_reward(torch.zeros(0, g), torch.zeros(0, g)).shape == (0,)     # zero-length batch
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros(E, A + 1))                          # the reference's `assert action.shape == (4,)`
+    with pytest.raises(ValueError):
+        env.reset(mask=torch.zeros(E + 1, dtype=torch.uint8))
+    with pytest.raises(XarmNativeError):
+        gym_xarm_amd.make(env_id, num_envs=0)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,A", ENVS)
+def test_an_env_does_not_depend_on_its_batch(env_id, A):
+    import torch
+    import gym_xarm_amd
+    ref = None
+    for E in (1, 33, 1000):
+        env = gym_xarm_amd.make(env_id, num_envs=E, seed=5)
+        env.reset()
+        gen = torch.Generator(device=env.device)
+        gen.manual_seed(1)
+        for _ in range(3):
+            a = torch.rand(1000, A, device=env.device, generator=gen)[:E] * 2 - 1
+            obs, rew, done, info = env.step(a)
+        o0 = obs["observation"][0].clone()
+        ref = o0 if ref is None else ref
+        assert torch.equal(o0, ref), "env 0 differs at batch size %d" % E
+        env.close()

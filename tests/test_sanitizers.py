@@ -20,6 +20,9 @@ void xh_step(int, uint64_t, int64_t, double, double, int, int, int64_t, double*,
 void xh_reach_init(int, uint64_t, int64_t, int, int64_t, double*);
 void xh_reach_reset(int, uint64_t, int64_t, int, int64_t, double*, const uint8_t*, double*, double*, double*);
 void xh_reach_step(int, uint64_t, int64_t, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*, int32_t*);
+void xh_ho_init(int, uint64_t, int64_t, double, int, int64_t, double*);
+void xh_ho_reset(int, uint64_t, int64_t, double, int, int64_t, double*, const uint8_t*, double*, double*, double*);
+void xh_ho_step(int, uint64_t, int64_t, double, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*);
 void xh_st_init(int, uint64_t, int64_t, int, int64_t, double*);
 void xh_st_reset(int, uint64_t, int64_t, int, int64_t, double*, const uint8_t*, double*, double*, double*);
 void xh_st_step(int, uint64_t, int64_t, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*);
@@ -54,6 +57,12 @@ int main() {
             for (int k = 0; k < ES * 8; k++) sa[k] = ((t * 5 + k * 11) % 21) / 10.0 - 1.0;
             xh_st_step(f32, 5, 0, 0, ES, ss, sa, so, sg, sd, rew, done, succ);
         }
+        // Handover: one env, reset (6 ticks) + one step (15 ticks)
+        double *hs = (double*)calloc(76, 8), *ho = (double*)calloc(29, 8);
+        xh_ho_init(f32, 9, 0, 0.5, 1, 1, hs);
+        xh_ho_reset(f32, 9, 0, 0.5, 1, 1, hs, 0, ho, ag, dg);
+        xh_ho_step(f32, 9, 0, 0.5, 1, 1, hs, sa, ho, ag, dg, rew, done, succ);
+        free(hs); free(ho);
         free(ss); free(so); free(sg); free(sd); free(sa);
     }
     printf("ok %f\n", st[0] + obs[0]);

@@ -119,6 +119,10 @@ def test_oracle_under_asan_ubsan(tmp_path):
             "e = O.OraclePnP(3, seed=2, init_grasp_rate=0.5); e.reset()\n"
             "[e.step(np.random.default_rng(k).uniform(-1.5, 1.5, (3, 4))) for k in range(5)]\n"
             "r = O.OracleReach(3, seed=2, reward_type='dense_diff'); r.reset(); r.step(np.ones((3, 4)))\n"
+            "h = O.OracleHandover(2, seed=2); h.reset(); h.step(np.full((2, 8), 0.5))\n"
+            "t = O.OracleStackTower(2, seed=2); t.reset(); s = t.get_state(); s[0, 57:60] = s[0, 54:57] + [0.03, 0.004, 0]\n"
+            "s[1, 57:60] = s[1, 54:57] + [0.001, 0.002, 0.05]; s[1, 67:71] = [0, 0, 0.38, 0.925]; t.set_state(s)\n"
+            "[t.step(np.random.default_rng(k).uniform(-1, 1, (2, 8))) for k in range(3)]\n"
             "print('ok')\n") % (ROOT, str(so))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,26 @@
+"""Soak: 1500 steps of the headline configuration (65 536 envs, auto-reset), finiteness and throughput drift."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, gym_xarm_amd
+E = 65536
+env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=11)
+env.reset()
+g = torch.Generator(device=env.device); g.manual_seed(5)
+ring = [torch.rand(E, 4, device=env.device, generator=g) * 2 - 1 for _ in range(32)]
+bad = 0
+succ = 0
+t0 = time.perf_counter()
+for k in range(1500):
+    obs, rew, done, info = env.step(ring[k % 32])
+    if k % 100 == 99:
+        torch.cuda.synchronize()
+        fin = bool(torch.isfinite(obs["observation"]).all())
+        bad += 0 if fin else 1
+        succ += int(info["is_success"].sum())
+        dt = time.perf_counter() - t0
+        print("steps %4d: %.3e env steps/s, finite %s, max|obs| %.1f, successes in this step %d" % (
+            k + 1, E * 100 / dt, fin, float(obs["observation"].abs().max()), int(info["is_success"].sum())), flush=True)
+        t0 = time.perf_counter()
+st = env.get_state()
+print("final state finite:", bool(torch.isfinite(st).all()), " episodes per env: %.1f" % float(st[:, 53].mean()))
+sys.exit(1 if bad or not bool(torch.isfinite(st).all()) else 0)

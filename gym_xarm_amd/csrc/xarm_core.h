@@ -1101,7 +1101,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
         for (int s = 0; s < NTS; s++) l = tp[s].id == i ? tp[s].lam[0] : l;
         st.lam_t[i] = l;
-        st.lam_p[i] = i < NP ? pp[i < NP ? i : 0].lam[0] : (T)0;
+        if (i < NP) st.lam_p[i] = pp[i < NP ? i : 0].lam[0];   // entries >= NP are not rows of this scene (0, or the lazy-reset stash)
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) { st.qd[i] = dq[i]; st.q[i] += dt * dq[i]; }
@@ -1268,6 +1268,73 @@ XARM_HD void env_step(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (
     success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
     reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
     done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
+}
+
+// Lazy auto-reset (opt-in, NOT the reference's VecEnv semantics): instead of running the reference's
+// PNP_RESET_TICKS + 1 reset ticks inside the step call in which an env finishes - six sequential ticks of latency for a
+// handful of envs while the rest of the GPU idles - a finished env spends its next six step calls on
+// those same ticks, one per call, next to the ordinary steps of all other envs.  The tick sequence and therefore the
+// state after the sixth call are exactly those of env_reset.  While resetting, `st.steps` holds -(ticks still to
+// run) and the env's action is ignored; phase = 1 marks the call in which the episode ended, 2 a reset tick
+// (transition to be masked by the learner; the sixth returns the first observation of the new episode).
+// The pose target of tick 5 is reused by the teleport tick (env_reset keeps it in a local); it is carried across the
+// two calls in lam_p[4..7] and goal[0..2], which are dead during a reset.
+template <typename T, typename Lds>
+XARM_HD void env_step_lazy(const EnvCfg &cfg, int64_t env, EnvState<T> &st, const T (&act)[4], T (&obs)[OBS_DIM], T &reward,
+                           bool &done, bool &success, int &phase, Lds lds) {
+    const bool resetting = st.steps < (T)0;
+    const int left = resetting ? -(int)st.steps : 0;          // reset ticks still to run, 6 .. 1
+    const bool teleport = resetting && left == 1;
+    T a[4], qt[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = clampT(act[k], (T)-1, (T)1);
+    Frame<T> f = frame_identity<T>();
+#pragma unroll
+    for (int i = 0; i < 7; i++) fk_advance(f, i, st.q[i]);
+    const T sc = (T)(xm::PNP_MAX_VEL * xm::PNP_ACTION_DT);
+    const V3<T> tstep = mk<T>(clampT(f.o.x + a[0] * sc, (T)xm::PNP_POS_LOW[0], (T)xm::PNP_POS_HIGH[0]),
+                              clampT(f.o.y + a[1] * sc, (T)xm::PNP_POS_LOW[1], (T)xm::PNP_POS_HIGH[1]),
+                              clampT(f.o.z + a[2] * sc, (T)xm::PNP_POS_LOW[2], (T)xm::PNP_POS_HIGH[2]));
+    const V3<T> start = mk<T>((T)xm::PNP_START_GRIPPER_POS[0], (T)xm::PNP_START_GRIPPER_POS[1], (T)xm::PNP_START_GRIPPER_POS[2]);
+    ik_solve(st.q, resetting ? start : tstep, qt);
+    const T g = clampT(st.q[7] + a[3] * (T)(xm::PNP_ACTION_DT * xm::PNP_MAX_GRIPPER_VEL), (T)xm::PNP_GRIPPER_LOW, (T)xm::PNP_GRIPPER_HIGH);
+    qt[7] = qt[8] = resetting ? (T)xm::PNP_RESET_FINGER_TARGET : g;
+    if (teleport) {
+        // the pose target stays the one of the previous tick; then respawn the object and draw the goal (:259-266, :124)
+#pragma unroll
+        for (int k = 0; k < 4; k++) qt[k] = st.lam_p[4 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) qt[4 + k] = st.goal[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) st.lam_p[4 + k] = (T)0;
+        T u[8];
+        sample_draws(cfg, env, (int64_t)st.episode + 1, u);
+        sample_object(cfg, u, st);
+        sample_goal(cfg, u, st);
+    } else if (resetting) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) st.lam_p[4 + k] = qt[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) st.goal[k] = qt[4 + k];
+    } else {
+        st.steps += (T)1;
+        st.mug = st.touch; // friction toggle from the LAST step's contacts (:212-218)
+    }
+    sim_tick<T, Lds>(st, qt, lds);
+    get_obs(st, obs);
+    const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
+    const T dist = xsqrt(dx * dx + dy * dy + dz * dz);
+    if (resetting) {
+        success = false; done = false; reward = (T)0; phase = 2;
+        st.steps = teleport ? (T)0 : (T)(-(left - 1));
+        if (teleport) st.episode += (T)1;
+    } else {
+        success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
+        reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
+        done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
+        phase = done ? 1 : 0;
+        if (done) st.steps = (T)(-(xm::PNP_RESET_TICKS + 1));
+    }
 }
 
 } // namespace xk

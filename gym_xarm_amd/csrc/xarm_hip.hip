@@ -138,6 +138,32 @@ __global__ __launch_bounds__(WG) void k_step(KParams P, const float *__restrict_
     }
 }
 
+// lazy auto-reset (xk::env_step_lazy): a finished env runs its reset ticks in its next six step calls; no reset launch,
+// no done list.  done_out carries the phase: 0 ordinary step, 1 the episode ended in this call, 2 reset tick.
+__global__ __launch_bounds__(WG) void k_step_lazy(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                  float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                  uint8_t *__restrict__ succ_out) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t e_in = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e_in >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e_in, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xk::OBS_DIM], reward;
+    bool done, success;
+    int phase;
+    xk::env_step_lazy<float, DevLds>(P.cfg, e_in, s, act, obs, reward, done, success, phase, lds);
+    const int64_t e = late_index(e_in);
+    store_state(P, e, s);
+    write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = (uint8_t)phase;
+    succ_out[e] = success ? 1 : 0;
+}
+
 // XarmPickAndPlace.reset for the envs in list[0 .. *count): thread i handles env list[i]
 __global__ __launch_bounds__(WG) void k_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                               float *__restrict__ obs_out, float *__restrict__ ag_out,
@@ -623,6 +649,9 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (stack && cfg->reward_type > 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower reward_type is 0 (sparse) or 1 (-d)");
     if (!reach && !stack && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
     if (handover && cfg->reward_type != 0) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover is sparse-only (reward_type is hard-wired, xarm_handover.py:40)");
+    if (cfg->auto_reset < 0 || cfg->auto_reset > XARM_AUTO_RESET_LAZY) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: auto_reset must be 0, 1 or XARM_AUTO_RESET_LAZY");
+    if (cfg->auto_reset == XARM_AUTO_RESET_LAZY && cfg->env_kind != XARM_ENV_PICK_AND_PLACE)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: lazy auto-reset is implemented for XarmPickAndPlace only");
     if (cfg->num_envs <= 0 || cfg->num_envs > (int64_t)1 << 30) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: num_envs out of range");
     if (cfg->reward_type < 0 || cfg->reward_type > 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported reward_type");
     if (!reach && !stack && cfg->goal_shape != XARM_GOAL_AIR && cfg->goal_shape != XARM_GOAL_GROUND)
@@ -740,6 +769,13 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
     const bool reach = h->cfg.env_kind == XARM_ENV_REACH, handover = h->cfg.env_kind == XARM_ENV_HANDOVER;
     const bool stack = h->cfg.env_kind == XARM_ENV_STACK_TOWER;
+    if (h->kp.auto_reset == XARM_AUTO_RESET_LAZY) {
+        k_step_lazy<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev);
+        if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+        h->step_index++;
+        HIPCHK(h, hipGetLastError());
+        return XARM_OK;
+    }
     if (stack)
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                        terminal_obs_dev, h->done_list, cnt, stale);

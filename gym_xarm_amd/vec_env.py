@@ -67,7 +67,10 @@ class XarmPickAndPlaceVecEnv:
         self.num_envs = int(num_envs)
         self._seed = int(seed)
         self._env_id_offset = int(env_id_offset)
-        self._auto_reset = bool(auto_reset)
+        # auto_reset: True = the reference's VecEnv semantics (reset inside the step call in which the episode ends),
+        # False = never, "lazy" = the six reset ticks are spread over the env's next six step calls (include/xarm_hip.h)
+        self._lazy = auto_reset == "lazy"
+        self._auto_reset = 2 if self._lazy else int(bool(auto_reset))
         self._h = C.c_void_p(0)
         self._create()
         d = _native.XarmDims()
@@ -129,6 +132,12 @@ class XarmPickAndPlaceVecEnv:
         rc = self._L.xarm_step(self._h, _ptr(self._actions), _ptr(self._obs), _ptr(self._ag), _ptr(self._dg),
                                _ptr(self._rew), _ptr(self._done), _ptr(self._succ), _ptr(self._term), self._stream())
         _native.check(self._L, self._h, rc, "xarm_step")
+        if self._lazy:
+            phase = self._done
+            done = (phase == 1).to(torch.uint8)
+            info = {"is_success": self._succ, "terminal_observation": self._obs, "resetting": phase == 2,
+                    "TimeLimit.truncated": (phase == 1) & (self._succ == 0)}
+            return self._obs_dict(), self._rew, done, info
         info = {"is_success": self._succ, "terminal_observation": self._term,
                 "TimeLimit.truncated": (self._done != 0) & (self._succ == 0)}
         self._extra_info(info)

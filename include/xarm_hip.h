@@ -46,6 +46,14 @@ extern "C" {
                                      obs 55, action 8, goal 9, reward_type 0 = -(d > 0.09) / 1 = -d (:124-129),
                                      50 steps (:43); step() itself never reports done (:111) */
 
+/* auto_reset = XARM_AUTO_RESET_LAZY (PickAndPlace only; NOT the reference's semantics, opt-in for throughput): an env that
+ * finishes an episode runs the reference's six reset ticks (xarm_pick_and_place.py:250-266) one per call in its next six
+ * xarm_step calls instead of inside the call in which it finished.  The tick sequence, and so the state the new episode
+ * starts from, is the same.  done[e] then reports the phase: 0 ordinary step, 1 the episode ended in this call (obs =
+ * terminal observation), 2 reset tick (action ignored, reward 0, to be masked by the learner; the sixth such call returns
+ * the first observation of the new episode).  No terminal_obs buffer is written. */
+#define XARM_AUTO_RESET_LAZY 2
+
 #define XARM_REWARD_SPARSE 0    /* (|ag-g| < 0.05) -> 1/0            :163-165 */
 #define XARM_REWARD_DENSE_O2G 1 /* -|ag-g|                           :176-177 */
 #define XARM_REWARD_DENSE 2     /* staged reach/grasp/lift reward    :166-175; uses the simulator's contact
@@ -69,7 +77,8 @@ typedef struct xarm_config {
     int32_t goal_shape;     /* XARM_GOAL_*   (config['goal_shape']) */
     float init_grasp_rate;  /* config['init_grasp_rate'] */
     float goal_ground_rate; /* config['goal_ground_rate'] */
-    int32_t auto_reset;     /* 1: envs that finish an episode in xarm_step are reset in the same call */
+    int32_t auto_reset;     /* 1: envs that finish an episode in xarm_step are reset in the same call (the reference's
+                               VecEnv semantics); XARM_AUTO_RESET_LAZY: see below */
     int32_t device;         /* HIP device ordinal */
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
     int32_t reserved;

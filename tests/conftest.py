@@ -80,6 +80,17 @@ class HostCore:
                        self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
         return st, obs, ag, dg, rew, done, succ
 
+    def step_lazy(self, state, actions, f32=1, **kw):
+        """lazy auto-reset step; the returned `done` array holds the phase (0 / 1 / 2)"""
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 24)), np.zeros((E, 3)), np.zeros((E, 3))
+        rew, done, succ = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self.L.xh_step_lazy(C.c_int(f32), *self._cfg(**kw), C.c_int64(E), self._p(st), self._p(a), self._p(obs),
+                            self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
+        return st, obs, ag, dg, rew, done, succ
+
     def reset(self, state, mask=None, f32=1, **kw):
         E = state.shape[0]
         st = np.array(state, dtype=np.float64, copy=True)

@@ -50,6 +50,20 @@ void do_step(const xk::EnvCfg &cfg, int64_t E, double *state, const double *act,
     }
 }
 template <typename T>
+void do_step_lazy(const xk::EnvCfg &cfg, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    for (int64_t e = 0; e < E; e++) {
+        xk::EnvState<T> s; T lds[xk::LDS_FLOATS]; HostLds<T> L{lds};
+        load(state + e * xk::STATE_DIM, s);
+        T a[4], o[xk::OBS_DIM], r; bool d, su; int phase;
+        for (int k = 0; k < 4; k++) a[k] = (T)act[e * 4 + k];
+        xk::env_step_lazy<T>(cfg, e, s, a, o, r, d, su, phase, L);
+        store(s, state + e * xk::STATE_DIM);
+        for (int k = 0; k < xk::OBS_DIM; k++) obs[e * xk::OBS_DIM + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = s.bp[k]; dg[e * 3 + k] = s.goal[k]; }
+        rew[e] = r; done[e] = (uint8_t)phase; succ[e] = su;
+    }
+}
+template <typename T>
 void do_reset(const xk::EnvCfg &cfg, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
     for (int64_t e = 0; e < E; e++) {
         if (mask && !mask[e]) continue;
@@ -230,6 +244,11 @@ void xh_reach_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, doub
 }
 #define CFGARGS uint64_t seed, int64_t off, double igr, double ggr, int gs, int rt
 void xh_init(int f32, CFGARGS, int64_t E, double *state) { auto c = mkcfg(seed, off, igr, ggr, gs, rt); if (f32) do_init<float>(c, E, state); else do_init<double>(c, E, state); }
+// lazy auto-reset step: `done` returns the phase (0 ordinary, 1 episode ended in this call, 2 reset tick)
+void xh_step_lazy(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    auto c = mkcfg(seed, off, igr, ggr, gs, rt);
+    if (f32) do_step_lazy<float>(c, E, state, act, obs, ag, dg, rew, done, succ); else do_step_lazy<double>(c, E, state, act, obs, ag, dg, rew, done, succ);
+}
 void xh_step(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
     auto c = mkcfg(seed, off, igr, ggr, gs, rt);
     if (f32) do_step<float>(c, E, state, act, obs, ag, dg, rew, done, succ); else do_step<double>(c, E, state, act, obs, ag, dg, rew, done, succ);

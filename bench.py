@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pnp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the extra measurement of the opt-in lazy auto-reset mode")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +147,36 @@ def main():
     kstep_ms = D.max_over_ranks(kstep_ms, device=dev)
     resets = D.sum_over_ranks(float(n_done.item()), device=dev)
 
+    # extra (pnp only): the opt-in lazy auto-reset mode (include/xarm_hip.h XARM_AUTO_RESET_LAZY) - a different contract
+    # from the reference's VecEnv, so it never feeds `value`; useful = env steps that are not reset ticks
+    lazy = None
+    if args.workload == "pnp" and not args.no_lazy:
+        env.close()
+        lenv = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=rank * E, device=dev, config=env_config, auto_reset="lazy")
+        lenv.reset()
+        for i in range(args.warmup):
+            lenv.step(ring[i % 64])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        useful = torch.zeros((), device=dev)
+        for i in range(args.steps):
+            _, _, _, linfo = lenv.step(ring[(args.warmup + i) % 64])
+            useful += (~linfo["resetting"]).sum()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ldt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        luse = D.sum_over_ranks(float(useful.item()), device=dev)
+        lazy = {"value": luse / ldt, "unit": "useful env steps/s (reset ticks excluded)", "ms_per_step": ldt / args.steps * 1e3,
+                "useful_fraction": luse / (total_envs * args.steps),
+                "note": "opt-in auto_reset='lazy': a finished env runs the reference's six reset ticks one per step call; "
+                        "same reset state, different VecEnv contract - not comparable with `value`"}
+        lenv.close()
+        env = None
     if rank == 0:
         value = total_envs * args.steps / dt
         algo_bytes = algo_bytes_per_step * E                     # one step-kernel launch processes E env steps
@@ -185,10 +216,13 @@ def main():
         }
         if valu is not None:
             out["roofline"]["valu"] = valu
+        if lazy is not None:
+            out["lazy_reset"] = lazy
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    env.close()
+    if env is not None:
+        env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -71,7 +71,7 @@ def test_cube_cube_host_matches_oracle(oracle, host):
 
 
 def test_stack_host_f64_matches_oracle(oracle, host):
-    E = 3
+    E = 2
     ora = oracle.OracleStackTower(E, seed=4)
     st = host.st_init(E, f32=0, seed=4)
     assert np.array_equal(st, ora.get_state())
@@ -79,7 +79,7 @@ def test_stack_host_f64_matches_oracle(oracle, host):
     o2, a2, d2 = ora.reset()
     assert np.abs(st - ora.get_state()).max() < 1e-12 and np.abs(obs - o2).max() < 1e-12 and np.array_equal(dg, d2)
     rng = np.random.default_rng(1)
-    for _ in range(3):
+    for _ in range(2):
         act = rng.uniform(-1.2, 1.2, (E, 8))
         st, obs, ag, dg, rew, done, succ = host.st_step(st, act, f32=0, seed=4)
         o2, a2, d2, r2, dn2, s2 = ora.step(act)
@@ -105,7 +105,7 @@ def test_stack_host_f64_contact_scenarios(oracle, host):
     st = ora.get_state()
     act = np.zeros((3, 8))
     act[2, 3] = -1
-    for _ in range(3):
+    for _ in range(2):
         st, obs, ag, dg, rew, done, succ = host.st_step(st, act, f32=0, seed=2)
         o2 = ora.step(act)[0]
         assert np.abs(st - ora.get_state()).max() < 1e-9, np.abs(st - ora.get_state()).max(0).argmax()

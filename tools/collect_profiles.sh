@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="$ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="$ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-lazy"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -- python3 $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python3 $BENCH > $OUT/pmc_write.log 2>&1

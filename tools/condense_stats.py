@@ -9,7 +9,7 @@ other = [0, 0.0]
 for r in rows:
     n = r["Name"]
     short = None
-    for k in ("k_step", "k_reset", "k_init", "k_substeps", "k_get_state", "k_set_state", "k_compute_reward", "k_compact_mask"):
+    for k in ("k_step_lazy", "k_step", "k_reset", "k_init", "k_substeps", "k_get_state", "k_set_state", "k_compute_reward", "k_compact_mask"):
         if "::" + k + "(" in n:
             short = k
     if short is None:

@@ -3,7 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gym_xarm_amd
 E = 65536
-env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=11)
+MODE = "lazy" if len(sys.argv) > 1 and sys.argv[1] == "lazy" else True
+env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=11, auto_reset=MODE)
 env.reset()
 g = torch.Generator(device=env.device); g.manual_seed(5)
 ring = [torch.rand(E, 4, device=env.device, generator=g) * 2 - 1 for _ in range(32)]

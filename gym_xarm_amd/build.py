@@ -15,8 +15,8 @@ SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h
 # -amdgpu-sched-strategy=iterative-ilp: the kernels run one wavefront per SIMD, so nothing hides the latency between
 # dependent instructions except the order of the wavefront's own instruction stream; the ILP-driven scheduler takes
 # the contact-path tick from 2.36 to 2.05 ms (tools/variant_time.sh; disabling post-RA scheduling costs +33 %).  Its
-# price: it raises register pressure until ~52 dwords of per-env state are parked in scratch across each substep's
-# sweep (208 B/lane, outside the Gauss-Seidel loop; +27 MB of L2<->fabric traffic per 65 536-env launch).
+# price: it raises register pressure until ~42 dwords of per-env state are parked in scratch across each substep's
+# sweep (168 B/lane, outside the Gauss-Seidel loop; +19 MB of L2<->fabric traffic per 65 536-env launch).
 # XARM_SCHED=default builds with LLVM's default scheduler instead (0 B scratch, ~13 % slower).
 _SCHED = [] if os.environ.get("XARM_SCHED", "ilp") == "default" else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"] + _SCHED

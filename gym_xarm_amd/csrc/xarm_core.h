@@ -1101,7 +1101,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
         for (int s = 0; s < NTS; s++) l = tp[s].id == i ? tp[s].lam[0] : l;
         st.lam_t[i] = l;
-        if (i < NP) st.lam_p[i] = pp[i < NP ? i : 0].lam[0];   // entries >= NP are not rows of this scene (0, or the lazy-reset stash)
+        st.lam_p[i] = i < NP ? pp[i < NP ? i : 0].lam[0] : (T)0;
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) { st.qd[i] = dq[i]; st.q[i] += dt * dq[i]; }
@@ -1311,16 +1311,18 @@ XARM_HD void env_step_lazy(const EnvCfg &cfg, int64_t env, EnvState<T> &st, cons
         sample_draws(cfg, env, (int64_t)st.episode + 1, u);
         sample_object(cfg, u, st);
         sample_goal(cfg, u, st);
-    } else if (resetting) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) st.lam_p[4 + k] = qt[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) st.goal[k] = qt[4 + k];
-    } else {
+    } else if (!resetting) {
         st.steps += (T)1;
         st.mug = st.touch; // friction toggle from the LAST step's contacts (:212-218)
     }
     sim_tick<T, Lds>(st, qt, lds);
+    if (resetting && !teleport) {
+        // stash this tick's pose target for the teleport tick (written after the tick: substep clears lam_p[4..7])
+#pragma unroll
+        for (int k = 0; k < 4; k++) st.lam_p[4 + k] = qt[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) st.goal[k] = qt[4 + k];
+    }
     get_obs(st, obs);
     const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
     const T dist = xsqrt(dx * dx + dy * dy + dz * dz);

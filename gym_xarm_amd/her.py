@@ -98,6 +98,7 @@ def collect(env, buffer, policy, steps, obs=None):
     """Roll `steps` env steps with policy(obs_dict) -> actions[E, A] and store them.  The env's tensors are reused
     from step to step, so the previous observation is cloned before stepping, and finished envs contribute their
     terminal observation (info['terminal_observation']) instead of the post-reset one."""
+    assert not getattr(env, "_lazy", False), "HER collection assumes the reference's in-call auto-reset (auto_reset=True)"
     if obs is None:
         obs = env.reset()
     for _ in range(steps):

@@ -87,10 +87,12 @@ class ActorCritic(nn.Module):
 
 
 def train(env_id="XarmReach-v0", num_envs=4096, updates=300, n_steps=5, gamma=0.99, lr=7e-4, seed=0, config=None, log_every=50,
-          quiet=False):
+          quiet=False, auto_reset=True):
+    """auto_reset="lazy" (PickAndPlace): transitions flagged info["resetting"] carry no reward and no gradient and cut the
+    return like an episode end - the env spends them on its reset ticks (include/xarm_hip.h XARM_AUTO_RESET_LAZY)"""
     import gym_xarm_amd
     torch.manual_seed(seed)
-    env = gym_xarm_amd.make(env_id, num_envs=num_envs, seed=seed, config=config)
+    env = gym_xarm_amd.make(env_id, num_envs=num_envs, seed=seed, config=config, auto_reset=auto_reset)
     venv = VecNormalize(env, gamma=gamma)
     dev = env.device
     model = ActorCritic(venv.dim, env.act_dim).to(dev)
@@ -99,12 +101,14 @@ def train(env_id="XarmReach-v0", num_envs=4096, updates=300, n_steps=5, gamma=0.
     hist, t0 = [], time.perf_counter()
     succ_sum, done_sum, raw_sum = torch.zeros((), device=dev), torch.zeros((), device=dev), torch.zeros((), device=dev)
     for it in range(1, updates + 1):
-        obs_buf, act_buf, rew_buf, done_buf = [], [], [], []
+        obs_buf, act_buf, rew_buf, done_buf, use_buf = [], [], [], [], []
         for _ in range(n_steps):
             with torch.no_grad():
                 a = model.dist(obs).sample()
             nobs, nrew, done, info, raw = venv.step(a.clamp(-1, 1))
-            obs_buf.append(obs); act_buf.append(a); rew_buf.append(nrew); done_buf.append(done.float())
+            resetting = info["resetting"].float() if "resetting" in info else torch.zeros_like(nrew)
+            obs_buf.append(obs); act_buf.append(a); rew_buf.append(nrew * (1.0 - resetting))
+            done_buf.append(torch.maximum(done.float(), resetting)); use_buf.append(1.0 - resetting)
             succ_sum += (info["is_success"].float() * done.float()).sum()
             done_sum += done.float().sum()
             raw_sum += raw.mean()
@@ -116,11 +120,12 @@ def train(env_id="XarmReach-v0", num_envs=4096, updates=300, n_steps=5, gamma=0.
                 ret = rew_buf[k] + gamma * ret * (1.0 - done_buf[k])
                 rets.append(ret)
             rets = torch.stack(rets[::-1])
-        O, A = torch.stack(obs_buf), torch.stack(act_buf)
+        O, A, U = torch.stack(obs_buf), torch.stack(act_buf), torch.stack(use_buf)
         values = model.value(O)
         adv = rets - values.detach()
         logp = model.dist(O).log_prob(A).sum(-1)
-        loss = -(adv * logp).mean() + 0.5 * ((rets - values) ** 2).mean()
+        n_use = U.sum().clamp(min=1.0)
+        loss = -(adv * logp * U).sum() / n_use + 0.5 * (((rets - values) ** 2) * U).sum() / n_use
         opt.zero_grad(set_to_none=True)
         loss.backward()
         nn.utils.clip_grad_norm_(model.parameters(), 0.5)
@@ -145,9 +150,10 @@ def main():
     ap.add_argument("--updates", type=int, default=300)
     ap.add_argument("--reward-type", default="dense")
     ap.add_argument("--save", default=None, help="safetensors file for the policy + VecNormalize statistics")
+    ap.add_argument("--lazy-reset", action="store_true", help="opt-in lazy auto-reset (PickAndPlace), masked in the update")
     args = ap.parse_args()
-    cfg = {"reward_type": args.reward_type, "GUI": False} if "Reach" in args.env else None
-    model, venv, hist = train(args.env, args.num_envs, args.updates, config=cfg)
+    cfg = {"reward_type": args.reward_type, "GUI": False} if ("Reach" in args.env or "PickAndPlace" in args.env) else None
+    model, venv, hist = train(args.env, args.num_envs, args.updates, config=cfg, auto_reset="lazy" if args.lazy_reset else True)
     if args.save:
         from safetensors.torch import save_file
         sd = {"policy." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}

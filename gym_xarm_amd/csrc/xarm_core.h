@@ -367,7 +367,8 @@ template <typename T> struct ArmDyn {
     V3<T> hc0, hc1, hc2; // hand (link7) frame axes
     V3<T> fo[2];       // finger frame origins
 };
-template <typename T, typename Lds, typename Scene>
+// OPSPACE = false (cooperative core, xarm_coop_core.h): only S is staged, T and A_hh are not formed.
+template <typename T, typename Lds, typename Scene, bool OPSPACE = true>
 XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, const int arm, ArmDyn<T> &A) {
     // ---------------- kinematics + world-frame RNEA / CRBA
     SV<T> S[7];      // joint motion axes about the world origin
@@ -521,7 +522,7 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
         dq[r] = qd_in[r] + dt * s;
     }
     // T = Minv[:, 0:7] S^T (9 x 6) -> LDS; A_hh = S T_a (6x6 sym) -> registers; T_f rows -> registers
-    {
+    if (OPSPACE) {
         T Tm[9][6];
 #pragma unroll
         for (int r = 0; r < 9; r++)
@@ -556,6 +557,13 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
         for (int r = 0; r < 9; r++)
 #pragma unroll
             for (int k = 0; k < 6; k++) lds[LDS_T + r * 6 + k] = Tm[r][k];
+        XARM_LDS_FENCE();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            lds[LDS_S + i * 6 + 0] = S[i].w.x; lds[LDS_S + i * 6 + 1] = S[i].w.y; lds[LDS_S + i * 6 + 2] = S[i].w.z;
+            lds[LDS_S + i * 6 + 3] = S[i].v.x; lds[LDS_S + i * 6 + 4] = S[i].v.y; lds[LDS_S + i * 6 + 5] = S[i].v.z;
+        }
         XARM_LDS_FENCE();
     }
     (void)ho;

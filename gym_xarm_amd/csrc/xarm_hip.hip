@@ -24,6 +24,7 @@
 #include "xarm_reach_core.h"
 #include "xarm_handover_core.h"
 #include "xarm_stack_core.h"
+#include "xarm_coop_core.h"
 
 namespace {
 
@@ -41,6 +42,7 @@ struct KParams {
     xk::EnvCfg cfg;
     int auto_reset;
     int state_dim;
+    int coop_limit;    // resets of at most this many envs run on the cooperative kernel (0: never)
     xr::EnvCfg rcfg;
     xh::EnvCfg hcfg;
 };
@@ -164,19 +166,54 @@ __global__ __launch_bounds__(WG) void k_step_lazy(KParams P, const float *__rest
     succ_out[e] = success ? 1 : 0;
 }
 
-// XarmPickAndPlace.reset for the envs in list[0 .. *count): thread i handles env list[i]
+// XarmPickAndPlace.reset for the envs in list[0 .. *count): thread i handles env list[i].  Counts of at most
+// P.coop_limit belong to k_reset_coop (launched beside this kernel; exactly one of the two does the work).
 __global__ __launch_bounds__(WG) void k_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                               float *__restrict__ obs_out, float *__restrict__ ag_out,
                                               float *__restrict__ dg_out) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
     const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n <= P.coop_limit) return;
     if (i >= n) return;
     const int64_t e_in = list ? (int64_t)list[i] : i;
     DevLds lds{smem + threadIdx.x};
     xk::EnvState<float> s;
     load_state(P, e_in, s);
     xk::env_reset<float, DevLds>(P.cfg, e_in, s, lds);
+    const int64_t e = late_index(e_in);
+    store_state(P, e, s);
+    if (obs_out) {
+        float obs[xk::OBS_DIM];
+        xk::get_obs(s, obs);
+        write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    }
+}
+
+// The same reset with one environment per DPP row of 16 lanes (xarm_coop_core.h): 4 environments per wavefront, the
+// Gauss-Seidel sweep spread over the row.  This is the latency-optimal form for the usual case - a handful to a few
+// thousand finished episodes per step - where k_reset would keep one wavefront busy for six sequential ticks while
+// the rest of the GPU idles.  Rows beyond the list shadow its last entry (the wavefront stays convergent) and store
+// nothing; lane 0 of a row writes the environment back.
+constexpr int COOP_ENVS = WG / xc::GL;
+__global__ __launch_bounds__(WG) void k_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                   float *__restrict__ obs_out, float *__restrict__ ag_out,
+                                                   float *__restrict__ dg_out) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n > P.coop_limit) return;
+    const int64_t i0 = (int64_t)blockIdx.x * COOP_ENVS;
+    if (i0 >= n) return;
+    const int64_t i_raw = i0 + threadIdx.x / xc::GL;
+    const bool live = i_raw < n;
+    const int64_t i = live ? i_raw : n - 1;
+    const int64_t e_in = list ? (int64_t)list[i] : i;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e_in, s);
+    xc::env_reset<float, DevLds>(G, P.cfg, e_in, s, lds);
+    if (!live || G.l != 0) return;
     const int64_t e = late_index(e_in);
     store_state(P, e, s);
     if (obs_out) {
@@ -624,6 +661,17 @@ static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
         if (_e != hipSuccess) return fail(h, XARM_E_HIP, #call ": %s", hipGetErrorString(_e)); \
     } while (0)
 
+// PickAndPlace reset of the envs in list[0 .. *count) (null: all): the cooperative kernel takes counts up to
+// kp.coop_limit, the one-env-per-lane kernel the rest; both are launched, the one out of its range exits at once.
+static void launch_pnp_reset(xarm_handle *h, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
+                             hipStream_t st) {
+    const int64_t cap = h->kp.num_envs < (int64_t)h->kp.coop_limit ? h->kp.num_envs : (int64_t)h->kp.coop_limit;
+    if (cap > 0)
+        k_reset_coop<<<dim3((unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    if (h->kp.num_envs > cap)
+        k_reset<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+}
+
 static void timing_flush(xarm_handle *h) {
     for (int i = 0; i < h->ev_n; i++) {
         float ms = 0.f;
@@ -674,6 +722,13 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.cfg.goal_shape = cfg->goal_shape;
     h->kp.cfg.reward_type = cfg->reward_type;
     h->kp.auto_reset = cfg->auto_reset;
+    // cooperative reset kernel (PickAndPlace): default cross-over measured on MI355X; 0 disables it
+    h->kp.coop_limit = 0;
+    if (cfg->env_kind == XARM_ENV_PICK_AND_PLACE) {
+        h->kp.coop_limit = cfg->reset_coop_limit > 0 ? cfg->reset_coop_limit : (cfg->reset_coop_limit < 0 ? 0 : XARM_RESET_COOP_LIMIT_DEFAULT);
+        const char *ev = getenv("XARM_RESET_COOP_LIMIT");
+        if (ev && *ev) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+    }
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
@@ -745,12 +800,12 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
-        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else launch_pnp_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
     } else {
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
-        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else launch_pnp_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
     }
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
@@ -793,7 +848,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else if (handover) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
-        else k_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
     }
     h->step_index++;
     HIPCHK(h, hipGetLastError());

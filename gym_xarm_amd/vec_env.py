@@ -50,9 +50,10 @@ class XarmPickAndPlaceVecEnv:
                                   int(self.config["num_obj"]), _native.REWARD_TYPES[self.config["reward_type"]],
                                   _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
                                   float(self.config["goal_ground_rate"]), int(self._auto_reset),
-                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0, 0)
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0,
+                                  int(self._reset_coop_limit))
 
-    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True):
+    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True, reset_coop_limit=0):
         cfg = self._check_config(config)
         self.config = cfg
         if cfg.get("GUI"):
@@ -69,6 +70,9 @@ class XarmPickAndPlaceVecEnv:
         self._env_id_offset = int(env_id_offset)
         # auto_reset: True = the reference's VecEnv semantics (reset inside the step call in which the episode ends),
         # False = never, "lazy" = the six reset ticks are spread over the env's next six step calls (include/xarm_hip.h)
+        # PickAndPlace: resets of at most this many envs per call run on the cooperative (16 lanes per env) kernel;
+        # 0 = the library default, < 0 = always the one-env-per-lane kernel (include/xarm_hip.h)
+        self._reset_coop_limit = int(reset_coop_limit)
         self._lazy = auto_reset == "lazy"
         self._auto_reset = 2 if self._lazy else int(bool(auto_reset))
         self._h = C.c_void_p(0)

@@ -81,8 +81,10 @@ typedef struct xarm_config {
                                VecEnv semantics); XARM_AUTO_RESET_LAZY: see below */
     int32_t device;         /* HIP device ordinal */
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
-    int32_t reserved;
+    int32_t reset_coop_limit; /* PickAndPlace: resets of at most this many envs per call run on the cooperative
+                               (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
 } xarm_config;
+#define XARM_RESET_COOP_LIMIT_DEFAULT 8192
 
 typedef struct xarm_dims_t {
     int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;

@@ -47,7 +47,8 @@ class HostCore:
         d = os.path.join(ROOT, "tests", "hostbuild")
         so = os.path.join(d, "libxarm_host.so")
         srcs = [os.path.join(d, "xarm_host.cpp")] + [os.path.join(ROOT, "gym_xarm_amd", "csrc", f) for f in (
-            "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_stack_core.h")]
+            "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_stack_core.h",
+            "xarm_coop_core.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
                                    "-o", so, srcs[0]])
@@ -79,6 +80,30 @@ class HostCore:
         self.L.xh_step(C.c_int(f32), *self._cfg(**kw), C.c_int64(E), self._p(st), self._p(a), self._p(obs),
                        self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
         return st, obs, ag, dg, rew, done, succ
+
+    def coop_step(self, state, actions, f32=1, **kw):
+        """xc::env_step: the 16-lanes-per-env impulse-space core (csrc/xarm_coop_core.h)"""
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 24)), np.zeros((E, 3)), np.zeros((E, 3))
+        rew, done, succ = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self.L.xh_coop_step(C.c_int(f32), *self._cfg(**kw), C.c_int64(E), self._p(st), self._p(a), self._p(obs),
+                            self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
+        return st, obs, ag, dg, rew, done, succ
+
+    def coop_reset(self, state, mask=None, f32=1, **kw):
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        obs, ag, dg = np.zeros((E, 24)), np.zeros((E, 3)), np.zeros((E, 3))
+        mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xh_coop_reset(C.c_int(f32), *self._cfg(**kw), C.c_int64(E), self._p(st), mk, self._p(obs), self._p(ag), self._p(dg))
+        return st, obs, ag, dg
+
+    def coop_substep(self, state, qt, n, f32=1):
+        st = np.array(state, dtype=np.float64, copy=True)
+        self.L.xh_coop_substep(C.c_int(f32), C.c_int64(st.shape[0]), self._p(st), self._p(np.ascontiguousarray(qt, dtype=np.float64)), C.c_int(n))
+        return st
 
     def step_lazy(self, state, actions, f32=1, **kw):
         """lazy auto-reset step; the returned `done` array holds the phase (0 / 1 / 2)"""

@@ -9,6 +9,7 @@
 #include "../../gym_xarm_amd/csrc/xarm_reach_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_handover_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_stack_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_coop_core.h"
 #include <pthread.h>
 #include <string.h>
 
@@ -87,6 +88,45 @@ template <typename T> void do_substep(int64_t E, double *state, const double *qt
         T t[9]; for (int k = 0; k < 9; k++) t[k] = (T)qt[e * 9 + k];
         const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
         for (int k = 0; k < n; k++) xk::substep<T>(s, t, dt, L);
+        store(s, state + e * xk::STATE_DIM);
+    }
+}
+// cooperative (16 lanes per env) core: the host LV<T> carries the 16 lane values, so one call runs the whole row
+template <typename T>
+void coop_step(const xk::EnvCfg &cfg, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    for (int64_t e = 0; e < E; e++) {
+        xk::EnvState<T> s; T lds[xk::LDS_FLOATS]; HostLds<T> L{lds};
+        load(state + e * xk::STATE_DIM, s);
+        T a[4], o[xk::OBS_DIM], r; bool d, su;
+        for (int k = 0; k < 4; k++) a[k] = (T)act[e * 4 + k];
+        xc::env_step<T>(xc::Grp(), cfg, s, a, o, r, d, su, L);
+        store(s, state + e * xk::STATE_DIM);
+        for (int k = 0; k < xk::OBS_DIM; k++) obs[e * xk::OBS_DIM + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = s.bp[k]; dg[e * 3 + k] = s.goal[k]; }
+        rew[e] = r; done[e] = d; succ[e] = su;
+    }
+}
+template <typename T>
+void coop_reset(const xk::EnvCfg &cfg, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        xk::EnvState<T> s; T lds[xk::LDS_FLOATS]; HostLds<T> L{lds};
+        load(state + e * xk::STATE_DIM, s);
+        xc::env_reset<T>(xc::Grp(), cfg, e, s, L);
+        store(s, state + e * xk::STATE_DIM);
+        T o[xk::OBS_DIM];
+        xk::get_obs(s, o);
+        for (int k = 0; k < xk::OBS_DIM; k++) obs[e * xk::OBS_DIM + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = s.bp[k]; dg[e * 3 + k] = s.goal[k]; }
+    }
+}
+template <typename T> void coop_substep(int64_t E, double *state, const double *qt, int n) {
+    for (int64_t e = 0; e < E; e++) {
+        xk::EnvState<T> s; T lds[xk::LDS_FLOATS]; HostLds<T> L{lds};
+        load(state + e * xk::STATE_DIM, s);
+        T t[9]; for (int k = 0; k < 9; k++) t[k] = (T)qt[e * 9 + k];
+        const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+        for (int k = 0; k < n; k++) xc::substep<T>(xc::Grp(), s, t, dt, L);
         store(s, state + e * xk::STATE_DIM);
     }
 }
@@ -257,6 +297,15 @@ void xh_reset(int f32, CFGARGS, int64_t E, double *state, const uint8_t *mask, d
     auto c = mkcfg(seed, off, igr, ggr, gs, rt);
     if (f32) do_reset<float>(c, E, state, mask, obs, ag, dg); else do_reset<double>(c, E, state, mask, obs, ag, dg);
 }
+void xh_coop_step(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    auto c = mkcfg(seed, off, igr, ggr, gs, rt);
+    if (f32) coop_step<float>(c, E, state, act, obs, ag, dg, rew, done, succ); else coop_step<double>(c, E, state, act, obs, ag, dg, rew, done, succ);
+}
+void xh_coop_reset(int f32, CFGARGS, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = mkcfg(seed, off, igr, ggr, gs, rt);
+    if (f32) coop_reset<float>(c, E, state, mask, obs, ag, dg); else coop_reset<double>(c, E, state, mask, obs, ag, dg);
+}
+void xh_coop_substep(int f32, int64_t E, double *state, const double *qt, int n) { if (f32) coop_substep<float>(E, state, qt, n); else coop_substep<double>(E, state, qt, n); }
 void xh_substep(int f32, int64_t E, double *state, const double *qt, int n) { if (f32) do_substep<float>(E, state, qt, n); else do_substep<double>(E, state, qt, n); }
 void xh_ik(int f32, const double *q, const double *target, double *out) { if (f32) do_ik<float>(q, target, out); else do_ik<double>(q, target, out); }
 }

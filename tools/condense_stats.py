@@ -9,9 +9,9 @@ other = [0, 0.0]
 for r in rows:
     n = r["Name"]
     short = None
-    for k in ("k_step_lazy", "k_step", "k_reset", "k_init", "k_substeps", "k_get_state", "k_set_state", "k_compute_reward", "k_compact_mask"):
-        if "::" + k + "(" in n:
-            short = k
+    m = __import__("re").search(r"::(k_[a-z_]+)\(", n)
+    if m:
+        short = m.group(1)
     if short is None:
         other[0] += int(r["Calls"]); other[1] += float(r["TotalDurationNs"]); continue
     print("%s,%s,%.3f,%.1f,%.1f,%.1f,%.2f" % (short, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,

@@ -2,14 +2,20 @@
 """Headline benchmark: env steps/sec of XarmPDPickAndPlace-v0 (BASELINE.json `metric`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack]
+                  [--scaling weak|strong] [--repeats R] [--episode-phase desync|lockstep]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one env step of EVERY environment of the job (one xarm_step call per rank), including
-the automatic resets of finished episodes.  Weak scaling: each rank owns `--envs-per-gpu` (default
-65 536, the configuration the metric is quoted on) independent environments, global env ids
-rank*E .. (rank+1)*E-1, no data-path collective.  Inputs are synthetic: a ring of
-64 pre-generated uniform[-1,1] action tensors resident in HBM, so the timed region contains no RNG
-and no host->device traffic.  Rank 0 prints ONE JSON line.
+the automatic resets of finished episodes.  `--scaling weak` (default, what `value` uses): each rank owns
+`--envs-per-gpu` (default 65 536, the configuration the metric is quoted on) independent environments, global env
+ids rank*E .. (rank+1)*E-1; `--scaling strong`: the same number of environments in TOTAL, split over the ranks
+(gym_xarm_amd.distributed.shard_range).  No data-path collective either way.  Inputs are
+synthetic: a ring of 64 pre-generated uniform[-1,1] action tensors resident in HBM, so the timed region contains no
+RNG and no host->device traffic.  The timed window of K steps is repeated `--repeats` times back to back (default 3);
+`value` is the MEDIAN window (max over ranks per window), the others are listed.  `--episode-phase desync` (default)
+spreads the per-env step counters uniformly over the episode length before the warm-up, so that time-limit resets
+arrive at their steady-state rate (E / max_episode_steps per step) instead of all E at once every 50th step;
+`lockstep` keeps the counters as reset() leaves them.  Rank 0 prints ONE JSON line.
 
 `--workload` selects one of the other BASELINE.json configs for the same measurement (same JSON schema, its own
 metric name): reach = config 2 (XarmReach-v0, 4 096 envs), stack = config 4 (XarmPDStackTower-v0, 8 192 envs per
@@ -83,6 +89,31 @@ def cpu_baseline(workload="pnp"):
             "reference": "unavailable (pybullet not importable)"}
 
 
+def timed_window(env, ring, first, steps, world, dev, dist, D, torch):
+    """time exactly `steps` calls of env.step between two barriers + synchronize; returns max-over-ranks seconds,
+    episodes finished, and the HIP-event averages of the step kernel and of the reset kernels (ms per call)"""
+    env.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_done = torch.zeros((), device=dev)
+    for i in range(steps):
+        obs, rew, done, info = env.step(ring[(first + i) % 64])
+        n_done += done.sum()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    kstep_ms_total, launches = env.timing_read()
+    reset_ms_total, _ = env.timing_read_reset()
+    kstep_ms = D.max_over_ranks(kstep_ms_total / max(launches, 1), device=dev)
+    reset_ms = D.max_over_ranks(reset_ms_total / max(launches, 1), device=dev)
+    resets = D.sum_over_ranks(float(n_done.item()), device=dev)
+    return dt, resets, kstep_ms, reset_ms, int(launches)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +121,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pnp")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--episode-phase", choices=["desync", "lockstep"], default="desync")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the extra measurement of the opt-in lazy auto-reset mode")
     args = ap.parse_args()
@@ -118,11 +152,20 @@ def main():
             dist.init_process_group(backend)
 
     env_id, default_E, act_dim, algo_bytes_per_step, kernel_name, _, _, env_config = WORKLOADS[args.workload]
-    E = args.envs_per_gpu or default_E
-    env = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=rank * E, device=dev, config=env_config)
+    n_cfg = args.envs_per_gpu or default_E
+    if args.scaling == "strong":
+        lo, hi = D.shard_range(n_cfg, rank, world)     # the configured env count is the TOTAL, split over the ranks
+        E, offset = hi - lo, lo
+    else:
+        E, offset = n_cfg, rank * n_cfg
+    env = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
+    T_ep = env.max_episode_steps
+    if args.episode_phase == "desync":
+        # steady state: episode phases uniform over the episode length, keyed by the global env id
+        env.set_episode_steps((torch.arange(E, device=dev) + offset) * 7919 % T_ep)
     n_done = torch.zeros((), device=dev)
     for i in range(args.warmup):
         # the warm-up runs exactly what the timed loop runs (torch loads the code object of a kernel at its first
@@ -130,36 +173,24 @@ def main():
         obs, rew, done, info = env.step(ring[i % 64])
         n_done += done.sum()
     torch.cuda.synchronize()
-    env.timing_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n_done = torch.zeros((), device=dev)
-    for i in range(args.steps):
-        obs, rew, done, info = env.step(ring[(args.warmup + i) % 64])
-        n_done += done.sum()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, device=dev)
+    windows = []
+    for r in range(max(1, args.repeats)):
+        windows.append(timed_window(env, ring, args.warmup + r * args.steps, args.steps, world, dev, dist, D, torch))
     total_envs = int(D.sum_over_ranks(E, device=dev))
-    kstep_ms_total, launches = env.timing_read()
-    kstep_ms = kstep_ms_total / max(launches, 1)
-    kstep_ms = D.max_over_ranks(kstep_ms, device=dev)
-    resets = D.sum_over_ranks(float(n_done.item()), device=dev)
+    order = sorted(range(len(windows)), key=lambda k: windows[k][0])
+    dt, resets, kstep_ms, reset_ms, launches = windows[order[len(order) // 2]]     # the median window
 
     # extra (pnp only): the opt-in lazy auto-reset mode (include/xarm_hip.h XARM_AUTO_RESET_LAZY) - a different contract
     # from the reference's VecEnv, so it never feeds `value`; useful = env steps that are not reset ticks
     lazy = None
     if args.workload == "pnp" and not args.no_lazy:
         env.close()
-        lenv = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=rank * E, device=dev, config=env_config, auto_reset="lazy")
+        lenv = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config, auto_reset="lazy")
         lenv.reset()
+        useful = torch.zeros((), device=dev)
         for i in range(args.warmup):
-            lenv.step(ring[i % 64])
+            _, _, _, linfo = lenv.step(ring[i % 64])
+            useful += (~linfo["resetting"]).sum()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -183,40 +214,64 @@ def main():
         env = None
     if rank == 0:
         value = total_envs * args.steps / dt
-        algo_bytes = algo_bytes_per_step * E                     # one step-kernel launch processes E env steps
-        achieved = algo_bytes / (kstep_ms * 1e-3) / 1e9
+        algo_bytes = algo_bytes_per_step * E                     # one xarm_step call processes E env steps per rank
+        call_ms = kstep_ms + reset_ms                            # the kernels of one xarm_step call
+        achieved = algo_bytes / (call_ms * 1e-3) / 1e9
+        step_only = algo_bytes / (kstep_ms * 1e-3) / 1e9
         traffic = None
+        pmc_data = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("%s_hbm_bytes_per_launch_%d" % (kernel_name, E))
+                pmc_data = json.load(open(pmc))
             except Exception:
-                traffic = None
-        # secondary ceiling (the one that actually binds): fp32 vector issue.  Wave-instruction count per launch
-        # from the committed SQ_INSTS_VALU PMC pass, 64 lanes x 2 flop upper bound per instruction.
+                pmc_data = {}
+        traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (kernel_name, E))
+        # secondary ceiling (the one that actually binds): fp32 vector issue.  FLOPs per env step are COUNTED (the
+        # kernel core instantiated with a counting scalar type, tools/count_flops.py -> profiles/flop_count.json);
+        # the wave-instruction count of the committed SQ_INSTS_VALU pass is kept beside it
         valu = None
-        if os.path.exists(pmc):
-            try:
-                n_valu = json.load(open(pmc)).get("%s_valu_wave_insts_per_launch_%d" % (kernel_name, E))
-                if n_valu:
-                    tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
-                    valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction)",
-                            "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu}
-            except Exception:
-                valu = None
+        flops = pmc_data.get("%s_counted_flops_per_env_step" % args.workload)
+        n_valu = pmc_data.get("%s_valu_wave_insts_per_launch_%d" % (kernel_name, E))
+        if flops:
+            tf = flops * E / (call_ms * 1e-3) / 1e12
+            valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (counted flops per env step x env steps / kernel time)",
+                    "frac": tf / VALU_PEAK_TFLOPS, "counted_flops_per_env_step": flops}
+            if n_valu:
+                valu["wave_insts_per_step_kernel_launch"] = n_valu
+        elif n_valu:
+            tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
+            valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction, step kernel only)",
+                    "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu}
+        reset_kernel = {"pnp": "k_reset_coop (<= 8192 finished envs per call) / k_reset", "reach": "k_reach_reset",
+                        "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
         out = {
             "metric": "env steps/sec (whole node), %s" % env_id, "value": value, "unit": "env steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAMES[args.workload],
                        "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": SUBSTEPS[args.workload], "solver_iterations": 50,
-                       "auto_reset": True, "episodes_reset_in_window": int(resets), "parallelism": "env-shard x%d, no collective" % world},
+                       "auto_reset": True, "episode_phase": args.episode_phase, "episodes_reset_in_window": int(resets),
+                       "resets_per_step": resets / args.steps, "steady_state_time_limit_resets_per_step": total_envs / T_ep,
+                       "parallelism": "env-shard x%d, no collective" % world},
+            "repeats": {"n": len(windows), "value_is": "median window",
+                        "env_steps_per_sec": [total_envs * args.steps / w[0] for w in windows],
+                        "min": total_envs * args.steps / max(w[0] for w in windows),
+                        "max": total_envs * args.steps / min(w[0] for w in windows)},
+            # the unit of work is one xarm_step call = step kernel + the reset kernels that follow it; SURVEY 8(d)'s
+            # algorithmic bytes per env step x E env steps per call, over the HIP-event time of those kernels
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                         "kernel_avg_ms": kstep_ms, "kernel_launches": int(launches),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "%s + %s (one xarm_step call)" % (kernel_name, reset_kernel),
+                         "kernel_avg_ms": call_ms, "kernel_launches": int(launches),
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "fused step: HBM is touched once per env step, the kernel is fp32-VALU/latency bound (DESIGN.md)"},
-            "kernel_only_env_steps_per_sec_per_gpu": E / (kstep_ms * 1e-3),
+                         "kernels": {kernel_name: {"avg_ms": kstep_ms, "share": kstep_ms / call_ms,
+                                                   "achieved_GBs": step_only, "frac": step_only / HBM_PEAK_GBS},
+                                     "reset": {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms}},
+                         "dominant_kernel": kernel_name if kstep_ms >= reset_ms else reset_kernel,
+                         "note": "fused step: HBM is touched once per env step, the kernels are fp32-VALU/latency bound (DESIGN.md); "
+                                 "`traffic` is the PMC figure of the step kernel"},
+            "kernel_only_env_steps_per_sec_per_gpu": E / (call_ms * 1e-3),
         }
         if valu is not None:
             out["roofline"]["valu"] = valu

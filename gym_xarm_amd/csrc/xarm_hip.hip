@@ -641,9 +641,9 @@ struct xarm_handle {
     // timing
     int timing;
     static constexpr int NEV = 1024;
-    hipEvent_t ev0[NEV], ev1[NEV];
+    hipEvent_t ev0[NEV], ev1[NEV], ev2[NEV];   // before the step kernel, after it, after the reset kernels
     int ev_n;
-    double ev_ms;
+    double ev_ms, ev_reset_ms;
     int64_t ev_launches;
     bool ev_created;
 };
@@ -672,12 +672,26 @@ static void launch_pnp_reset(xarm_handle *h, const int *list, const int *count, 
         k_reset<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
 }
 
+// The handle's kernels, events and buffers live on cfg.device.  Every entry point makes that device current for its
+// own duration and restores the caller's (torch's) current device on return, so a handle can be created and used
+// while another device is current, and several handles on different GPUs can share a process.
+struct DeviceGuard {
+    int prev;
+    bool switched;
+    explicit DeviceGuard(int dev) : prev(-1), switched(false) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
+};
+#define DEVGUARD(h) DeviceGuard _guard((h)->cfg.device)
+
 static void timing_flush(xarm_handle *h) {
     for (int i = 0; i < h->ev_n; i++) {
         float ms = 0.f;
-        if (hipEventSynchronize(h->ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]) == hipSuccess) {
+        if (hipEventSynchronize(h->ev2[i]) == hipSuccess && hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]) == hipSuccess) {
             h->ev_ms += ms;
             h->ev_launches++;
+            if (hipEventElapsedTime(&ms, h->ev1[i], h->ev2[i]) == hipSuccess) h->ev_reset_ms += ms;
         }
     }
     h->ev_n = 0;
@@ -707,7 +721,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, XARM_E_NODEVICE, "%s", "xarm_create: no HIP device");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: bad device ordinal");
-    HIPCHK(nullptr, hipSetDevice(cfg->device));
+    DeviceGuard _guard(cfg->device);
     xarm_handle *h = new (std::nothrow) xarm_handle();
     if (!h) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: out of host memory");
     memset(h, 0, sizeof *h);
@@ -765,9 +779,10 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
 
 int xarm_destroy(xarm_handle *h) {
     if (!h) return XARM_OK;
+    DEVGUARD(h);
     hipDeviceSynchronize();
     if (h->ev_created)
-        for (int i = 0; i < xarm_handle::NEV; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
+        for (int i = 0; i < xarm_handle::NEV; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); hipEventDestroy(h->ev2[i]); }
     if (h->kp.state) hipFree(h->kp.state);
     if (h->done_list) hipFree(h->done_list);
     if (h->done_count) hipFree(h->done_count);
@@ -791,6 +806,7 @@ int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
 
 int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *ag_dev, float *dg_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
+    DEVGUARD(h);
     if (obs_dev && (!ag_dev || !dg_dev)) return fail(h, XARM_E_INVALID, "%s", "xarm_reset: goal buffers required with obs");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(h->kp.stride / WG);
@@ -814,6 +830,7 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
 int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *ag_dev, float *dg_dev, float *reward_dev,
               uint8_t *done_dev, uint8_t *success_dev, float *terminal_obs_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
+    DEVGUARD(h);
     if (!actions_dev || !obs_dev || !ag_dev || !dg_dev || !reward_dev || !done_dev || !success_dev)
         return fail(h, XARM_E_INVALID, "%s", "xarm_step: null buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -826,7 +843,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     const bool stack = h->cfg.env_kind == XARM_ENV_STACK_TOWER;
     if (h->kp.auto_reset == XARM_AUTO_RESET_LAZY) {
         k_step_lazy<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev);
-        if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+        if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
         h->step_index++;
         HIPCHK(h, hipGetLastError());
         return XARM_OK;
@@ -843,13 +860,14 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else
         k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                 terminal_obs_dev, h->done_list, cnt, stale);
-    if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+    if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
     if (h->kp.auto_reset) {
         if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else if (handover) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
     }
+    if (timed) { HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
     h->step_index++;
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
@@ -857,6 +875,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
 
 int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev, int64_t n, float *out_dev, void *stream) {
     if (!h) return XARM_E_INVALID;
+    DEVGUARD(h);
     if (n < 0 || (n > 0 && (!ag_dev || !g_dev || !out_dev))) return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: bad argument");
     if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) {
         if (n == 0) return XARM_OK;
@@ -888,6 +907,7 @@ int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev,
 
 int xarm_get_state(xarm_handle *h, float *state_dev, void *stream) {
     if (!h || !state_dev) return XARM_E_INVALID;
+    DEVGUARD(h);
     const int64_t n = h->kp.num_envs * h->kp.state_dim;
     k_get_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
     HIPCHK(h, hipGetLastError());
@@ -895,6 +915,7 @@ int xarm_get_state(xarm_handle *h, float *state_dev, void *stream) {
 }
 int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
     if (!h || !state_dev) return XARM_E_INVALID;
+    DEVGUARD(h);
     const int64_t n = h->kp.num_envs * h->kp.state_dim;
     k_set_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, state_dev);
     HIPCHK(h, hipGetLastError());
@@ -903,6 +924,7 @@ int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
 
 int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
     if (!h || !steps_dev) return XARM_E_INVALID;
+    DEVGUARD(h);
     const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (int)xh::H_STEPS :
                       (h->cfg.env_kind == XARM_ENV_STACK_TOWER ? (int)xs::K_STEPS : (int)xk::S_STEPS));
     k_episode_steps<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, field, steps_dev);
@@ -912,6 +934,7 @@ int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
 
 int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, void *stream) {
     if (!h || !qtarget_dev || n < 0) return XARM_E_INVALID;
+    DEVGUARD(h);
     if (h->cfg.env_kind != XARM_ENV_PICK_AND_PLACE) return fail(h, XARM_E_INVALID, "%s", "xarm_debug_substeps: PickAndPlace only");
     k_substeps<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, (hipStream_t)stream>>>(h->kp, qtarget_dev, n);
     HIPCHK(h, hipGetLastError());
@@ -920,21 +943,32 @@ int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, voi
 
 int xarm_timing_enable(xarm_handle *h, int32_t enable) {
     if (!h) return XARM_E_INVALID;
+    DEVGUARD(h);
     if (enable && !h->ev_created) {
         for (int i = 0; i < xarm_handle::NEV; i++) {
             HIPCHK(h, hipEventCreate(&h->ev0[i]));
             HIPCHK(h, hipEventCreate(&h->ev1[i]));
+            HIPCHK(h, hipEventCreate(&h->ev2[i]));
         }
         h->ev_created = true;
     }
-    if (enable) { h->ev_n = 0; h->ev_ms = 0; h->ev_launches = 0; }
+    if (enable) { h->ev_n = 0; h->ev_ms = 0; h->ev_reset_ms = 0; h->ev_launches = 0; }
     h->timing = enable;
     return XARM_OK;
 }
 int xarm_timing_read(xarm_handle *h, double *ms_total, int64_t *launches) {
     if (!h || !ms_total || !launches) return XARM_E_INVALID;
+    DEVGUARD(h);
     timing_flush(h);
     *ms_total = h->ev_ms;
+    *launches = h->ev_launches;
+    return XARM_OK;
+}
+int xarm_timing_read_reset(xarm_handle *h, double *reset_ms_total, int64_t *launches) {
+    if (!h || !reset_ms_total || !launches) return XARM_E_INVALID;
+    DEVGUARD(h);
+    timing_flush(h);
+    *reset_ms_total = h->ev_reset_ms;
     *launches = h->ev_launches;
     return XARM_OK;
 }

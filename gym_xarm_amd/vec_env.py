@@ -169,6 +169,13 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, self._L.xarm_episode_steps(self._h, _ptr(out), self._stream()), "xarm_episode_steps")
         return out
 
+    def set_episode_steps(self, steps):
+        """Overwrite the per-env step counter (int [E]) - e.g. to desynchronise the episodes of a freshly reset
+        batch so that time-limit resets arrive at their steady-state rate instead of in one burst."""
+        s = self.get_state()
+        s[:, self.state_dim - 2] = torch.as_tensor(steps, device=self.device).to(torch.float32)
+        self.set_state(s)
+
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
@@ -253,6 +260,12 @@ class XarmPickAndPlaceVecEnv:
     def timing_read(self):
         ms, n = C.c_double(0), C.c_int64(0)
         _native.check(self._L, self._h, self._L.xarm_timing_read(self._h, C.byref(ms), C.byref(n)), "xarm_timing_read")
+        return ms.value, n.value
+
+    def timing_read_reset(self):
+        """(total ms, calls) of the reset kernels launched inside step() since timing_enable"""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _native.check(self._L, self._h, self._L.xarm_timing_read_reset(self._h, C.byref(ms), C.byref(n)), "xarm_timing_read_reset")
         return ms.value, n.value
 
     def close(self):

@@ -128,6 +128,8 @@ int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, voi
 /* optional kernel timing: HIP events recorded around the step kernel on the caller's stream */
 int xarm_timing_enable(xarm_handle *h, int32_t enable);
 int xarm_timing_read(xarm_handle *h, double *step_kernel_ms_total, int64_t *launches);
+/* same for the reset kernels that follow the step kernel inside xarm_step (auto_reset): total ms over `launches` calls */
+int xarm_timing_read_reset(xarm_handle *h, double *reset_kernels_ms_total, int64_t *launches);
 
 const char *xarm_last_error(const xarm_handle *h);
 const char *xarm_version(void);

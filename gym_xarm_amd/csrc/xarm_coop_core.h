@@ -295,6 +295,8 @@ XARM_HD void lane_delassus_base(const Setup<T> &S, int l, const T (&R)[R_N], T (
     const T imb = (T)(1.0 / xk::PnpScene::OBJ_MASS);
 #pragma unroll
     for (int k = 0; k < 4; k++) invd[k] = (T)0;
+    T diag0 = (T)1, diag1 = (T)1;
+    bool act0 = false;
     // ---- table rows: M^-1 J^T touches the object only
 #pragma unroll
     for (int s = 0; s < NTS; s++)
@@ -305,9 +307,10 @@ XARM_HD void lane_delassus_base(const Setup<T> &S, int l, const T (&R)[R_N], T (
             const V3<T> bl = d * imb, ba = symmul(S.Iinv, cross(S.tr[s], d));
             const T a0 = R[R_J0 + 0] * bl.x + R[R_J0 + 1] * bl.y + R[R_J0 + 2] * bl.z + R[R_J0 + 3] * ba.x + R[R_J0 + 4] * ba.y + R[R_J0 + 5] * ba.z;
             nA0[C0_T + r] = -a0;
-            const bool act = S.tid[s] >= 0;
-            invd[0] = l == r ? (act ? (T)1 / a0 : (T)0) : invd[0];
+            diag0 = l == r ? a0 : diag0;
+            act0 = l == r ? S.tid[s] >= 0 : act0;
         }
+    invd[0] = act0 ? (T)1 / diag0 : (T)0;   // one division for the row this lane owns
     // ---- single-joint rows: M^-1 J^T is a signed combination of columns of Minv
 #pragma unroll
     for (int r = 0; r < NA1; r++) {
@@ -317,13 +320,16 @@ XARM_HD void lane_delassus_base(const Setup<T> &S, int l, const T (&R)[R_N], T (
 #pragma unroll
         for (int d = 0; d < 9; d++) a1 += R[R_J1 + d] * B[d];
         nA1[C1_A + r] = -a1;
-        invd[1] = l == r ? (T)1 / a1 : invd[1];
+        diag1 = l == r ? a1 : diag1;
     }
+    invd[1] = l < NA1 ? (T)1 / diag1 : (T)0;
 }
 // the entries that exist only with pad rows (slot 2) and / or arm-limit rows (slot 3)
 template <typename T, bool PAD, bool LA>
 XARM_HD void lane_delassus_extra(const Setup<T> &S, int l, const T (&R)[R_N], T (&nA1)[C1_N], T (&nA2)[C2_N], T (&nA3)[C1_N], T (&invd)[4]) {
     const T imb = (T)(1.0 / xk::PnpScene::OBJ_MASS);
+    T diag3 = (T)1;
+    bool act3 = false;
     if (PAD) {
 #pragma unroll
         for (int s = 0; s < NTS; s++)
@@ -351,8 +357,9 @@ XARM_HD void lane_delassus_extra(const Setup<T> &S, int l, const T (&R)[R_N], T 
         if (r >= NA1) nA1[c1] = -a1;
         if (PAD) nA2[(r < NA1 ? C2_A + r : C2_L + (r - NA1))] = -a2;
         if (LA) nA3[c1] = -a3;
-        if (r >= NA1) invd[3] = l == r - NA1 ? (S.la_sg[r - NA1] != (T)0 ? (T)1 / a3 : (T)0) : invd[3];
+        if (r >= NA1) { diag3 = l == r - NA1 ? a3 : diag3; act3 = l == r - NA1 ? S.la_sg[r - NA1] != (T)0 : act3; }
     }
+    if (LA) invd[3] = act3 ? (T)1 / diag3 : (T)0;
 }
 
 // ---------------------------------------------------------------------------------------------

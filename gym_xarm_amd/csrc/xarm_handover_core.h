@@ -35,6 +35,7 @@ struct EnvCfg {
     int64_t env_id_offset;
     float same_side_rate;
     int goal_shape; // 1 = 'ground'
+    int reward_type; // 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199)
 };
 
 struct HandoverScene {
@@ -168,8 +169,28 @@ XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds
 }
 
 // act = this arm's 4 action entries (:249-256)
+// staged dense reward (:184-199), evaluated identically by both lanes of the env: grip_k = hand COM of arm k -
+// eef2grip_offset (this lane's from arm_obs, the other arm's from its lane), if_k = the grasp flags _set_action read
+// before the step's simulation (:263-264 = st.mug).  The reference's last branch (only arm 2 holds the object) reads
+// an undefined `d` (:199) and raises; d = |achieved_goal - goal| here, the distance its docstring's stage 7 means.
+template <typename T, typename Xchg>
+XARM_HD T dense_reward(const Lane<T> &L, int arm, T d_og, Xchg x) {
+    T o8[8];
+    arm_obs(L, arm, o8);
+    const V3<T> g1 = mk<T>(x.from0(o8[0]), x.from0(o8[1]), x.from0(o8[2])), g2 = mk<T>(x.from1(o8[0]), x.from1(o8[1]), x.from1(o8[2]));
+    const bool if1 = x.from0(L.st.mug) > (T)0.5, if2 = x.from1(L.st.mug) > (T)0.5;
+    const V3<T> ag = mk<T>(L.st.bp[0], L.st.bp[1], L.st.bp[2]);
+    const V3<T> e1 = g1 - ag + mk<T>((T)0.06, (T)0, (T)0), e2 = g2 - ag + mk<T>((T)-0.06, (T)0, (T)0);
+    const T d1 = xk::xsqrt(xk::dot(e1, e1)), d2 = xk::xsqrt(xk::dot(e2, e2));
+    const T k = (T)(1.0 / 2.25);
+    if (!if1 && !if2) return (T)0.25 * ((T)1 - xk::xtanh(d1)) * k;
+    if (if1 && !if2) return ag.z > (T)0.05 ? ((T)1 + (T)0.25 * ((T)1 - xk::xtanh(d2))) * k : (T)0.5 * k;
+    if (if1 && if2) return (T)1.5 * k;
+    return ((T)2 + (T)0.25 * ((T)1 - xk::xtanh(d_og))) * k;
+}
+
 template <typename T, typename Lds, typename Xchg>
-XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x) {
+XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
     L.st.steps += (T)1;
     T a[4], qt[9];
 #pragma unroll
@@ -204,6 +225,7 @@ XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &
     const T dist = xk::xsqrt(dx * dx + dy * dy + dz * dz);
     success = dist < (T)xm::HO_DISTANCE_THRESHOLD;
     reward = dist > (T)xm::HO_DISTANCE_THRESHOLD ? (T)-1 : (T)0;   // -sum(d > thr) for one object (:177-181)
+    if (reward_type == 1) reward = dense_reward<T, Xchg>(L, arm, dist, x);
     done = success || ((int)L.st.steps == xm::HO_MAX_EPISODE_STEPS);
 }
 

@@ -223,6 +223,47 @@ __global__ __launch_bounds__(WG) void k_reset_coop(KParams P, const int *__restr
     }
 }
 
+// XarmPickAndPlace.step with one environment per 16-lane row (xarm_coop_core.h) - the launch for batches that leave
+// most SIMDs without a wavefront under the one-env-per-lane mapping (num_envs <= kp.coop_step_limit): 16x the
+// wavefronts and a ~3x shorter tick.  Same outputs and done list as k_step.
+__global__ __launch_bounds__(WG) void k_step_coop(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                  float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                  uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                  int *__restrict__ done_list, int *__restrict__ done_count,
+                                                  int *__restrict__ stale_count) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stale_count) *stale_count = 0;
+    const int64_t e_raw = (int64_t)blockIdx.x * COOP_ENVS + threadIdx.x / xc::GL;
+    const bool live = e_raw < P.num_envs;
+    const int64_t e_in = live ? e_raw : P.num_envs - 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e_in, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xk::OBS_DIM], reward;
+    bool done, success;
+    xc::env_step<float, DevLds>(G, P.cfg, s, act, obs, reward, done, success, lds);
+    if (!live || G.l != 0) return;
+    const int64_t e = late_index(e_in);
+    store_state(P, e, s);
+    write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = done ? 1 : 0;
+    succ_out[e] = success ? 1 : 0;
+    if (done && P.auto_reset) {
+        if (term_obs) {
+            float4 *o = reinterpret_cast<float4 *>(term_obs + e * xk::OBS_DIM);
+#pragma unroll
+            for (int k = 0; k < xk::OBS_DIM / 4; k++) o[k] = make_float4(obs[4 * k], obs[4 * k + 1], obs[4 * k + 2], obs[4 * k + 3]);
+        }
+        const int pos = atomicAdd(done_count, 1);
+        done_list[pos] = (int)e;
+    }
+}
+
 // test hook: n internal substeps toward fixed joint targets (no action / IK / obs logic)
 __global__ __launch_bounds__(WG) void k_substeps(KParams P, const float *__restrict__ qt_in, int n) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    xh::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg());
+    xh::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
     const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -636,6 +677,7 @@ struct xarm_handle {
     int *done_list;   // [E]
     int *done_count;  // [2] ping-pong counters
     int *mask_count;  // [1]
+    int coop_step_limit; // PickAndPlace: batches of at most this many envs step on k_step_coop
     uint64_t step_index;
     char err[512];
     // timing
@@ -710,7 +752,8 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (stack && cfg->num_obj != 3) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower has num_obj == 3 (xarm_stack_tower.py:19)");
     if (stack && cfg->reward_type > 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower reward_type is 0 (sparse) or 1 (-d)");
     if (!reach && !stack && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
-    if (handover && cfg->reward_type != 0) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover is sparse-only (reward_type is hard-wired, xarm_handover.py:40)");
+    if (handover && cfg->reward_type != 0 && cfg->reward_type != XARM_REWARD_DENSE)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover reward_type is sparse (hard-wired in the reference, xarm_handover.py:40) or dense (:184-199)");
     if (cfg->auto_reset < 0 || cfg->auto_reset > XARM_AUTO_RESET_LAZY) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: auto_reset must be 0, 1 or XARM_AUTO_RESET_LAZY");
     if (cfg->auto_reset == XARM_AUTO_RESET_LAZY && cfg->env_kind != XARM_ENV_PICK_AND_PLACE)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: lazy auto-reset is implemented for XarmPickAndPlace only");
@@ -743,11 +786,20 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         const char *ev = getenv("XARM_RESET_COOP_LIMIT");
         if (ev && *ev) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
+    // cooperative step kernel: pays while the one-env-per-lane launch would leave SIMDs empty (measured cross-over,
+    // DESIGN.md 5); XARM_STEP_COOP_LIMIT overrides, 0 disables
+    h->coop_step_limit = cfg->env_kind != XARM_ENV_PICK_AND_PLACE || cfg->step_coop_limit < 0 ? 0 :
+                         (cfg->step_coop_limit > 0 ? cfg->step_coop_limit : XARM_STEP_COOP_LIMIT_DEFAULT);
+    {
+        const char *ev = getenv("XARM_STEP_COOP_LIMIT");
+        if (ev && *ev && cfg->env_kind == XARM_ENV_PICK_AND_PLACE) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+    }
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
     h->kp.hcfg.same_side_rate = cfg->same_side_rate;
     h->kp.hcfg.goal_shape = cfg->goal_shape;
+    h->kp.hcfg.reward_type = cfg->reward_type == XARM_REWARD_DENSE ? 1 : 0;
     h->kp.rcfg.seed = cfg->seed;
     h->kp.rcfg.env_id_offset = cfg->env_id_offset;
     h->kp.rcfg.reward_type = cfg->reward_type;
@@ -857,6 +909,9 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else if (reach)
         k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                       terminal_obs_dev, h->done_list, cnt, stale);
+    else if (h->kp.num_envs <= (int64_t)h->coop_step_limit)
+        k_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, stale);
     else
         k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                 terminal_obs_dev, h->done_list, cnt, stale);
@@ -884,6 +939,8 @@ int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev,
         return XARM_OK;
     }
     if (h->cfg.env_kind == XARM_ENV_HANDOVER) {
+        if (h->cfg.reward_type == XARM_REWARD_DENSE)
+            return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense' depends on the grasp flags and gripper positions and cannot be relabelled");
         if (n == 0) return XARM_OK;
         k_ho_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
         HIPCHK(h, hipGetLastError());

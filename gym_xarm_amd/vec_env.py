@@ -51,9 +51,10 @@ class XarmPickAndPlaceVecEnv:
                                   _native.GOAL_SHAPES[self.config["goal_shape"]], float(self.config["init_grasp_rate"]),
                                   float(self.config["goal_ground_rate"]), int(self._auto_reset),
                                   self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0,
-                                  int(self._reset_coop_limit))
+                                  int(self._reset_coop_limit), int(self._step_coop_limit), 0)
 
-    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True, reset_coop_limit=0):
+    def __init__(self, num_envs, config=None, device=None, seed=0, env_id_offset=0, auto_reset=True, reset_coop_limit=0,
+                 step_coop_limit=0):
         cfg = self._check_config(config)
         self.config = cfg
         if cfg.get("GUI"):
@@ -73,6 +74,8 @@ class XarmPickAndPlaceVecEnv:
         # PickAndPlace: resets of at most this many envs per call run on the cooperative (16 lanes per env) kernel;
         # 0 = the library default, < 0 = always the one-env-per-lane kernel (include/xarm_hip.h)
         self._reset_coop_limit = int(reset_coop_limit)
+        # same for the step kernel: batches of at most this many envs step on the cooperative kernel (0 = default)
+        self._step_coop_limit = int(step_coop_limit)
         self._lazy = auto_reset == "lazy"
         self._auto_reset = 2 if self._lazy else int(bool(auto_reset))
         self._h = C.c_void_p(0)
@@ -331,13 +334,16 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
             raise NotImplementedError("this build supports num_obj == 1")
         if cfg["use_stand"]:
             raise NotImplementedError("use_stand=True (a static stand under the goal) is not built")
+        # the reference hard-wires reward_type = 'sparse' (xarm_handover.py:40); its staged 'dense' branch (:184-199) is
+        # offered as an opt-in config key (the undefined `d` of its last stage = object-to-goal distance)
         cfg.setdefault("reward_type", "sparse")
-        if cfg["reward_type"] != "sparse":
-            raise NotImplementedError("XarmHandover hard-wires reward_type='sparse' (xarm_handover.py:40)")
+        if cfg["reward_type"] not in ("sparse", "dense"):
+            raise NotImplementedError("XarmHandover reward_type %r" % (cfg["reward_type"],))
         return cfg
 
     def _native_config(self):
-        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 1, 0,
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 1,
+                                  _native.REWARD_TYPES[self.config["reward_type"]],
                                   1 if self.config["goal_shape"] == "ground" else 0, 0.0, 0.0, int(self._auto_reset),
                                   self.device.index if self.device.index is not None else torch.cuda.current_device(),
                                   float(self.config["same_side_rate"]), 0)

@@ -83,8 +83,14 @@ typedef struct xarm_config {
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
     int32_t reset_coop_limit; /* PickAndPlace: resets of at most this many envs per call run on the cooperative
                                (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
-} xarm_config;
+    int32_t step_coop_limit;  /* PickAndPlace: a handle of at most this many envs also STEPS on the cooperative kernel
+                                 (the one-env-per-lane launch would leave most SIMDs without a wavefront);
+                                 0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never */
+    int32_t reserved;
+} xarm_config;                /* 72 bytes */
 #define XARM_RESET_COOP_LIMIT_DEFAULT 8192
+/* PickAndPlace handles of at most this many envs step on the cooperative kernel as well (env XARM_STEP_COOP_LIMIT) */
+#define XARM_STEP_COOP_LIMIT_DEFAULT 8192
 
 typedef struct xarm_dims_t {
     int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;

@@ -1462,6 +1462,18 @@ int xo_ho_reset(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state,
     }
     return 0;
 }
+double xo_ho_dense_reward(const double *grip1, const double *grip2, int if1, int if2, const double *ag, const double *g) {
+    /* xarm_handover.py:185-199 */
+    real d1v[3] = {grip1[0] - ag[0] + 0.06, grip1[1] - ag[1], grip1[2] - ag[2]};
+    real d2v[3] = {grip2[0] - ag[0] - 0.06, grip2[1] - ag[1], grip2[2] - ag[2]};
+    real d1 = v3_norm(d1v), d2 = v3_norm(d2v);
+    if (!if1 && !if2) return 0.25 * (1 - tanh(1.0 * d1)) / 2.25;
+    if (if1 && !if2) return ag[2] > 0.05 ? (1.0 + 0.25 * (1 - tanh(1.0 * d2))) / 2.25 : 0.5 / 2.25;
+    if (if1 && if2) return 1.5 / 2.25;
+    real dg[3];
+    v3_sub(dg, ag, g);
+    return (2.0 + 0.25 * (1 - tanh(1.0 * v3_norm(dg)))) / 2.25;   /* `d` undefined in the reference (:199): object-to-goal */
+}
 int xo_ho_compute_reward(const xo_ho_cfg *c, int64_t n, const double *ag, const double *g, double *out) {
     for (int64_t i = 0; i < n; i++) {
         real d[3];
@@ -1511,7 +1523,11 @@ int xo_ho_step(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state, 
         v3_sub(d, ag + e * 3, dg + e * 3);
         real dist = v3_norm(d);
         success[e] = (uint8_t)(dist < c->distance_threshold);
-        reward[e] = -(dist > c->distance_threshold ? 1.0 : 0.0);
+        if (c->reward_type == 1) {
+            const real *o = obs + e * XO_HO_OBS_DIM;   /* hand COM - eef2grip of both arms: obs[13:16], obs[21:24] */
+            reward[e] = xo_ho_dense_reward(o + 13, o + 21, st[H_MUG] > 0.5, st[H_MUG + 1] > 0.5, ag + e * 3, dg + e * 3);
+        } else
+            reward[e] = -(dist > c->distance_threshold ? 1.0 : 0.0);
         done[e] = (uint8_t)(success[e] || ((int)st[H_STEPS] == c->max_episode_steps));
     }
     return 0;

@@ -140,12 +140,17 @@ typedef struct {
     double finger_motor_force, distance_threshold, obj_half[3], eef2grip[3];
     double table_x_min, table_x_max, table_half_y, ground_z; /* tables cover table_x_min <= |x| <= table_x_max */
     int32_t reset_ticks, max_episode_steps;
+    int32_t reward_type, reserved; /* 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199) */
 } xo_ho_cfg;
 int xo_ho_init(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state);
 int xo_ho_reset(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,
                 double *ag, double *dg);
 int xo_ho_step(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const double *actions, double *obs,
                double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success);
+/* staged dense reward of xarm_handover.py:184-199 (N = 1): grip_k = hand COM of arm k - eef2grip_offset, if_k = the grasp
+ * flags _set_action set before the step's simulation (:263-264).  The reference's last branch (only arm 2 holds the
+ * object) reads an undefined `d` and raises; here d = |achieved_goal - goal|, the distance the docstring's stage 7 means. */
+double xo_ho_dense_reward(const double *grip1, const double *grip2, int if1, int if2, const double *ag, const double *g);
 /* sparse reward of xarm_handover.py:177-183 for N = 1 over n rows */
 int xo_ho_compute_reward(const xo_ho_cfg *cfg, int64_t n, const double *ag, const double *g, double *out);
 /* ---- XarmPDStackTower-v0 (xarm_stack_tower.py), two xarm7_pd arms + three cubes ---- */

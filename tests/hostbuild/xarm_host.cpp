@@ -226,7 +226,7 @@ template <typename T> void *ho_thread(void *p) {
         T r = 0; bool d = false, su = false;
         if (J.mode == 0) {
             T a[4]; for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
-            xh::lane_step<T>(L, J.arm, a, r, d, su, hl, x);
+            xh::lane_step<T>(L, J.arm, a, r, d, su, hl, x, J.cfg.reward_type);
         } else xh::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
         T o8[8];
         xh::arm_obs(L, J.arm, o8);
@@ -256,7 +256,9 @@ template <typename T> void ho_run(int mode, const xh::EnvCfg &cfg, int64_t E, do
 }
 
 extern "C" {
-static xh::EnvCfg hcfg(uint64_t seed, int64_t off, double ssr, int gs) { xh::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.same_side_rate = (float)ssr; c.goal_shape = gs; return c; }
+static int g_ho_reward_type = 0;
+void xh_ho_set_reward_type(int rt) { g_ho_reward_type = rt; }   // 0 sparse, 1 the staged dense reward
+static xh::EnvCfg hcfg(uint64_t seed, int64_t off, double ssr, int gs) { xh::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.same_side_rate = (float)ssr; c.goal_shape = gs; c.reward_type = g_ho_reward_type; return c; }
 void xh_ho_init(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state) {
     auto c = hcfg(seed, off, ssr, gs);
     for (int64_t e = 0; e < E; e++) for (int a = 1; a >= 0; a--) {

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_struct_layout_matches_header():
     from gym_xarm_amd import _native
-    assert C.sizeof(_native.XarmConfig) == 64 and C.sizeof(_native.XarmDims) == 24
+    assert C.sizeof(_native.XarmConfig) == 72 and C.sizeof(_native.XarmDims) == 24
     src = open(HDR).read()
     fields = re.findall(r"^\s+(?:u?int\d+_t|float)\s+(\w+);", src[src.index("typedef struct xarm_config"):src.index("} xarm_config;")], flags=re.M)
     assert fields == [f[0] for f in _native.XarmConfig._fields_]

@@ -23,6 +23,26 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+class _Maker:
+    """gx.make with the PickAndPlace kernel family pinned: 'lane' = one env per lane for step and reset (k_step /
+    k_reset, what a 65 536-env batch steps on), 'coop' = the 16-lanes-per-env kernels (k_step_coop / k_reset_coop,
+    the default for the batch sizes of these tests)"""
+
+    def __init__(self, gx, family):
+        self.gx, self.family, self.vec_env = gx, family, gx.vec_env
+
+    def make(self, env_id, **kw):
+        if self.family == "lane":
+            kw.setdefault("step_coop_limit", -1)
+            kw.setdefault("reset_coop_limit", -1)
+        return self.gx.make(env_id, **kw)
+
+
+@pytest.fixture(scope="module", params=["lane", "coop"])
+def gxk(request, gx):
+    return _Maker(gx, request.param)
+
+
 def test_native_library_is_loaded(gx):
     """the product path maps libxarm_hip.so and nothing of the oracle (fresh interpreter: other test modules of this
     session load the oracle as their checker)"""
@@ -39,11 +59,11 @@ def test_native_library_is_loaded(gx):
     env.close()
 
 
-def test_init_and_reset_match_oracle(gx, oracle, parity):
+def test_init_and_reset_match_oracle(gxk, oracle, parity):
     E = 256
     kw = dict(init_grasp_rate=0.25, goal_ground_rate=0.5)
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=21, auto_reset=False,
-                  config=dict(gx.vec_env.CONFIG_DEFAULTS, **kw))
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=21, auto_reset=False,
+                  config=dict(gxk.vec_env.CONFIG_DEFAULTS, **kw))
     ora = oracle.OraclePnP(E, seed=21, **kw)
     np.testing.assert_allclose(_np(env.get_state()), ora.state, atol=1e-6)
     obs = env.reset()
@@ -59,11 +79,11 @@ def test_init_and_reset_match_oracle(gx, oracle, parity):
 
 
 @pytest.mark.parametrize("key,seed", [("rand", 7), ("grasp", 1)])
-def test_step_replays_golden_rollout(gx, golden_rollout, parity, key, seed):
+def test_step_replays_golden_rollout(gxk, golden_rollout, parity, key, seed):
     g = golden_rollout
     S, A = g[key + "_states"], g[key + "_actions"]
     E = S.shape[1]
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=seed, auto_reset=False)
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=seed, auto_reset=False)
     n_flag, n_all = 0, 0
     for t in range(A.shape[0]):
         env.set_state(S[t])
@@ -84,10 +104,10 @@ def test_step_replays_golden_rollout(gx, golden_rollout, parity, key, seed):
     env.close()
 
 
-def test_live_oracle_rollout_with_sensitivity(gx, oracle, parity):
+def test_live_oracle_rollout_with_sensitivity(gxk, oracle, parity):
     """fresh seeds, 512 envs, 6 steps after reset: HIP vs oracle from identical injected states"""
     E = 512
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=99, auto_reset=False)
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=99, auto_reset=False)
     ora = oracle.OraclePnP(E, seed=99)
     env.reset()
     gen = torch.Generator().manual_seed(3)
@@ -167,9 +187,9 @@ def test_spaces_rollout_like_reference_test_py(gx):
     env.close()
 
 
-def test_auto_reset_semantics(gx):
+def test_auto_reset_semantics(gxk):
     E = 128
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=8)
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=8)
     env.reset()
     st = env.get_state()
     st[:32, 52] = 49                       # these finish on the next step
@@ -225,13 +245,13 @@ def test_full_size_properties_65536(gx):
     assert (st[:, 52] == 3).all() | (full[3] != 0).any()
 
 
-def test_dense_reward_on_grasp_rollout(gx, oracle, golden_rollout, parity):
+def test_dense_reward_on_grasp_rollout(gxk, oracle, golden_rollout, parity):
     """reward_type='dense' (:166-175): staged reward incl. the contact-flag branches, HIP vs oracle"""
     g = golden_rollout
     S, A = g["grasp_states"], g["grasp_actions"]
     E = S.shape[1]
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=1, auto_reset=False,
-                  config=dict(gx.vec_env.CONFIG_DEFAULTS, reward_type="dense"))
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=1, auto_reset=False,
+                  config=dict(gxk.vec_env.CONFIG_DEFAULTS, reward_type="dense"))
     ora = oracle.OraclePnP(E, seed=1, reward_type="dense")
     seen = set()
     for t in range(A.shape[0]):
@@ -248,10 +268,10 @@ def test_dense_reward_on_grasp_rollout(gx, oracle, golden_rollout, parity):
     env.close()
 
 
-def test_auto_reset_matches_oracle_step_then_reset(gx, oracle):
+def test_auto_reset_matches_oracle_step_then_reset(gxk, oracle):
     """auto-reset path (k_step -> done list -> k_reset) against oracle.step followed by oracle.reset(mask)"""
     E = 128
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=31, config=dict(gx.vec_env.CONFIG_DEFAULTS, goal_shape="ground"))
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=31, config=dict(gxk.vec_env.CONFIG_DEFAULTS, goal_shape="ground"))
     ora = oracle.OraclePnP(E, seed=31, goal_shape="ground")
     env.reset()
     for _ in range(12):                       # let the objects settle, arm at rest
@@ -278,12 +298,12 @@ def test_auto_reset_matches_oracle_step_then_reset(gx, oracle):
     env.close()
 
 
-def test_scripted_pick_and_lift_rate(gx, tmp_path):
+def test_scripted_pick_and_lift_rate(gxk, tmp_path):
     """behavioural regression (cf. the reference's _run_demo :310-349): the closed-loop scripted policy lifts
     most objects that do not start under the gripper; also snapshot / restore of the simulator state"""
     from gym_xarm_amd.policies import lift_rate, PickAndLiftPolicy
     E = 2048
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=5, auto_reset=False)
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=5, auto_reset=False)
     rate = lift_rate(env)
     assert rate > 0.4, rate   # objects spawned under the gripper (~25 %) are thrown off the table by the reset
     snap = str(tmp_path / "state.safetensors")
@@ -297,12 +317,12 @@ def test_scripted_pick_and_lift_rate(gx, tmp_path):
     env.close()
 
 
-def test_rollout_statistics_match_oracle(gx, oracle):
+def test_rollout_statistics_match_oracle(gxk, oracle):
     """Past contact onset trajectories diverge (chaotic contact dynamics), so long-horizon parity is asserted on
     distributions (SURVEY.md 7 'Hard parts'): 2048 envs x 30 random steps from the same seeds, HIP vs oracle."""
     from concurrent.futures import ThreadPoolExecutor
     E, T, W = 2048, 30, 16
-    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=123, auto_reset=False)
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=123, auto_reset=False)
     env.reset()
     acts = [torch.rand(E, 4, generator=torch.Generator().manual_seed(100 + t)) * 2 - 1 for t in range(T)]
     for t in range(T):

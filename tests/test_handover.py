@@ -98,6 +98,51 @@ def test_hostcore_lane_pair_f32_within_tolerance(hostcore, groll, parity):
         parity.compare(st[:, CONT], g["states"][t + 1][sub][:, CONT], g["sens"][t][sub], what="handover f32 t=%d" % t, frac_tight=0.5, max_exempt=0.4)
 
 
+def test_dense_reward_matches_reference_formula(oracle, gref):
+    """staged dense reward (xarm_handover.py:184-199): the three branches the reference can evaluate agree with its
+    own code; the fourth (only arm 2 grasps) raises NameError there (`d` undefined, :199) and is the object-to-goal
+    distance here"""
+    import ctypes as C
+    g = gref
+    L = oracle.lib()
+    L.xo_ho_dense_reward.restype = C.c_double
+    dp = C.POINTER(C.c_double)
+    off = np.array([0, 0, 0.088 - 0.021])
+    seen = set()
+    for i in range(g["dense_reward"].shape[0]):
+        g1 = np.ascontiguousarray(g["dense_hand_com_1"][i] - off)
+        g2 = np.ascontiguousarray(g["dense_hand_com_2"][i] - off)
+        ag, gg = np.ascontiguousarray(g["dense_achieved_goal"][i]), np.ascontiguousarray(g["dense_goal"][i])
+        r = L.xo_ho_dense_reward(g1.ctypes.data_as(dp), g2.ctypes.data_as(dp), int(g["dense_if_1"][i]), int(g["dense_if_2"][i]),
+                                 ag.ctypes.data_as(dp), gg.ctypes.data_as(dp))
+        if g["dense_reference_raises"][i]:
+            assert not g["dense_if_1"][i] and g["dense_if_2"][i]
+            d = np.linalg.norm(ag - gg)
+            assert abs(r - (2.0 + 0.25 * (1 - np.tanh(d))) / 2.25) < 1e-15
+            seen.add(3)
+        else:
+            assert abs(r - g["dense_reward"][i]) < 1e-15, i
+            seen.add(int(g["dense_if_1"][i]) + 2 * int(g["dense_if_1"][i] and g["dense_if_2"][i]))
+    assert seen == {0, 1, 3}
+
+
+def test_dense_reward_hostcore_f64_equals_oracle(oracle, hostcore, groll):
+    """along the scripted hand-over (all four stages occur): oracle.step(dense) vs the lane-pair core"""
+    g = groll
+    sub = slice(0, 10)
+    ora = oracle.OracleHandover(10, seed=2, reward_type="dense")
+    stages = set()
+    for t in range(0, g["actions"].shape[0], 2):
+        ora.set_state(g["states"][t][sub])
+        o = ora.step(g["actions"][t][sub])
+        st, obs, ag, dg, rew, done, succ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=0, seed=2, rt=1)
+        ok = g["sens"][t][sub] < 1e-2
+        np.testing.assert_allclose(rew[ok], o[3][ok], atol=1e-8)
+        f = g["states"][t][sub][:, 70:72]          # touch flags before the step = the grasp flags the reward reads
+        stages |= set((f[:, 0] + 2 * f[:, 1]).astype(int)[ok])
+    assert stages == {0, 1, 2, 3}
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_gpu_handover_replays_golden_rollout(groll, parity):
@@ -182,3 +227,30 @@ def test_gpu_scripted_handover_rate():
     rate = handover_rate(env, steps=40)
     env.close()
     assert rate > 0.06, rate     # ~0.12-0.13 measured; the reference controller is crude (no alignment of the grasp)
+
+
+@pytest.mark.gpu
+def test_gpu_handover_dense_reward(oracle, groll):
+    """reward_type='dense' through the C ABI against the oracle on the scripted hand-over; relabelling is refused"""
+    import torch
+    import gym_xarm_amd as gx
+    g = groll
+    E = g["states"].shape[1]
+    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=2, auto_reset=False, config=dict(gx.vec_env.HANDOVER_CONFIG_DEFAULTS, reward_type="dense"))
+    ora = oracle.OracleHandover(E, seed=2, reward_type="dense")
+    stages, n = set(), 0
+    for t in range(g["actions"].shape[0]):
+        env.set_state(g["states"][t])
+        ora.set_state(g["states"][t])
+        obs, rew, done, info = env.step(torch.tensor(g["actions"][t], dtype=torch.float32))
+        o = ora.step(g["actions"][t])
+        ok = g["sens"][t] < 1e-3
+        np.testing.assert_allclose(rew.cpu().numpy()[ok], o[3][ok], atol=3e-4)
+        f = g["states"][t][:, 70:72]
+        stages |= set((f[:, 0] + 2 * f[:, 1]).astype(int)[ok])
+        n += ok.sum()
+    assert stages == {0, 1, 2, 3} and n > 0.6 * E * g["actions"].shape[0]
+    assert float(rew.max()) <= 1.0 + 1e-6 and float(rew.min()) >= 0.0           # staged reward is scaled into [0, 1]
+    with pytest.raises(Exception, match="relabel"):
+        env.compute_reward(torch.zeros(2, 3), torch.zeros(2, 3))
+    env.close()

@@ -49,7 +49,8 @@ def test_gpu_lazy_reset_equals_strict_reset_and_masks(coop):
     import torch
     import gym_xarm_amd
     E, K = 256, 14
-    strict = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=4, auto_reset=True, reset_coop_limit=0 if coop else -1)
+    strict = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=4, auto_reset=True, reset_coop_limit=0 if coop else -1,
+                                step_coop_limit=-1)       # the lazy mode steps one env per lane: same step kernel family
     lazy = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=4, auto_reset="lazy")
     strict.reset(); lazy.reset()
     s = strict.get_state(); s[:64, 52] = 47; strict.set_state(s); lazy.set_state(s)     # 64 envs hit the step limit at call 2

@@ -174,6 +174,35 @@ def handover():
     out["is_success"] = np.array([cls._is_success(self, ag[i], g[i]) for i in range(n)])
     steps = np.array([1, 99, 100])
     out["done"] = np.array([[(s == 100) or bool(out["is_success"][i]) for s in steps] for i in range(n)], dtype=np.uint8)  # :138 with TimeLimit(100)
+    # the staged dense reward (:184-199): reads the simulator through self._p and the grasp flags of _set_action; the
+    # reference's fourth branch (only arm 2 grasps) raises NameError (`d` undefined, :199) - recorded as such
+    class FakeClient:
+        def __init__(self):
+            self.hand = {1: np.zeros(3), 2: np.zeros(3)}
+
+        def getLinkState(self, body, link):
+            return (tuple(self.hand[body]),)
+    fake = FakeClient()
+    nd = 384
+    hand1 = rng.uniform([-0.35, -0.2, 0.1], [0.05, 0.2, 0.3], size=(nd, 3))
+    hand2 = rng.uniform([-0.05, -0.2, 0.1], [0.35, 0.2, 0.3], size=(nd, 3))
+    if1, if2 = rng.random(nd) < 0.5, rng.random(nd) < 0.4
+    agd = np.where((rng.random(nd) < 0.5)[:, None], hand1 - [0, 0, 0.067], hand2 - [0, 0, 0.067]) + rng.normal(scale=0.04, size=(nd, 3))
+    agd[:, 2] = np.where(rng.random(nd) < 0.5, rng.uniform(0.0, 0.05, nd), rng.uniform(0.05, 0.25, nd))
+    gd = rng.uniform([-0.28, -0.18, 0.025], [0.28, 0.18, 0.2], size=(nd, 3))
+    dense, raised = np.zeros(nd), np.zeros(nd, np.uint8)
+    for i in range(nd):
+        fake.hand[1], fake.hand[2] = hand1[i], hand2[i]
+        self = SimpleNamespace(reward_type="dense", distance_threshold=0.05, config={"num_obj": 1}, _p=fake, xarm_1=1, xarm_2=2,
+                               gripper_base_index=9, eef2grip_offset=[0, 0, 0.088 - 0.021], if_xarm1_grasp=bool(if1[i]), if_xarm2_grasp=bool(if2[i]))
+        try:
+            dense[i] = float(cls.compute_reward(self, agd[i], gd[i], {}))
+        except NameError:
+            raised[i] = 1
+            dense[i] = np.nan
+    assert raised.sum() == ((~if1) & if2).sum() and raised.sum() > 20
+    out.update(dense_hand_com_1=hand1, dense_hand_com_2=hand2, dense_if_1=if1.astype(np.uint8), dense_if_2=if2.astype(np.uint8),
+               dense_achieved_goal=agd, dense_goal=gd, dense_reward=dense, dense_reference_raises=raised)
     np.savez(os.path.join(OUT, "handover_reward_reference.npz"), **out)
     print("wrote handover_reward_reference.npz")
 

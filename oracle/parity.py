@@ -17,12 +17,18 @@ import numpy as np
 CONT = slice(0, 31)    # q, qd, box pose and velocities
 LAM = slice(34, 50)    # warm-start impulses
 ATOL, RTOL, K_SENS, EPS = 5e-4, 2e-4, 300.0, 1e-6
-# A sensitivity above this means the 1e-6 input perturbation was amplified > 5e4 times within one env
+# the sensitivity allowance K * sens never exceeds this: a transition conditioned badly enough to need more is either
+# exempt (sens > SENS_EXEMPT, counted and bounded by max_exempt) or a failure - it cannot hide an O(1) error
+ALLOW_CAP = 1e-2
+# A sensitivity above this means the 1e-6 input perturbation was amplified > 1e4 times within one env
 # step: the transition sits on a discontinuity of the contact geometry (which box face a buried pad
 # sphere is pushed out of, which four corners form the table manifold, btPlaneSpace1's branch).
 # Two float64 implementations that agree to 1e-14 per substep disagree by O(1) there, so such envs
-# are exempt from the value comparison (their count is bounded instead).
-SENS_EXEMPT = 0.05
+# are exempt from the value comparison (their count is bounded instead).  The probe (two draws of a +-1e-6
+# perturbation) underestimates the worst-case response of a transition by a small factor, so the line is drawn at
+# ALLOW_CAP / 3: an env is either held to an allowance of at most ~3x its measured sensitivity, capped at ALLOW_CAP,
+# or exempt and counted - never granted an O(0.1) allowance.
+SENS_EXEMPT = ALLOW_CAP / 3
 
 
 def perturb(state, rng, eps=EPS):
@@ -48,7 +54,7 @@ def oracle_step_with_sens(ora, state, actions, n_perturb=2, seed=0):
     return (nxt,) + tuple(out) + (sens,)
 
 
-def compare(x, ref, sens, atol=ATOL, rtol=RTOL, k=K_SENS, frac_tight=0.85, max_exempt=0.15, what="state"):
+def compare(x, ref, sens, atol=ATOL, rtol=RTOL, k=K_SENS, frac_tight=0.85, max_exempt=0.15, what="state", cap=ALLOW_CAP):
     """x, ref: [E, n]; sens: [E].  Raises AssertionError with a report, returns stats dict."""
     x = np.asarray(x, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
@@ -57,7 +63,7 @@ def compare(x, ref, sens, atol=ATOL, rtol=RTOL, k=K_SENS, frac_tight=0.85, max_e
     bound_tight = atol + rtol * np.abs(ref)
     tight = (err <= bound_tight).all(axis=1)
     exempt = sens > SENS_EXEMPT
-    ok = (err <= bound_tight + k * sens[:, None]).all(axis=1) | exempt
+    ok = (err <= bound_tight + np.minimum(k * sens, cap)[:, None]).all(axis=1) | exempt
     stats = dict(max_err=float(err[~exempt].max()) if (~exempt).any() else 0.0,
                  median_env_err=float(np.median(err.max(axis=1))),
                  frac_tight=float(tight.mean()), frac_ok=float(ok.mean()), frac_exempt=float(exempt.mean()),

@@ -91,7 +91,7 @@ def test_step_replays_golden_rollout(gxk, golden_rollout, parity, key, seed):
         st = _np(env.get_state()).astype(np.float64)
         sens = g[key + "_sens"][t]
         parity.compare(st[:, parity.CONT], S[t + 1][:, parity.CONT], sens, what="%s t=%d" % (key, t),
-                       frac_tight=0.6 if key == "rand" else 0.5, max_exempt=0.15 if key == "rand" else 0.5)
+                       frac_tight=0.9 if key == "rand" else 0.75, max_exempt=0.15 if key == "rand" else 0.25)   # grasp: 4 envs, one may sit on a discontinuity
         ok = sens < 1e-3
         np.testing.assert_allclose(_np(obs["observation"])[ok], g[key + "_obs"][t][ok], atol=2e-3)
         assert np.array_equal(_np(rew)[ok], g[key + "_rew"][t][ok].astype(np.float32))   # sparse reward: exact
@@ -118,7 +118,7 @@ def test_live_oracle_rollout_with_sensitivity(gxk, oracle, parity):
         r = parity.oracle_step_with_sens(ora, st0, a.numpy().astype(np.float64), seed=t)
         nxt, o_obs, o_ag, o_dg, o_rew, o_done, o_succ, sens = r
         st = _np(env.get_state()).astype(np.float64)
-        stats = parity.compare(st[:, parity.CONT], nxt[:, parity.CONT], sens, what="live t=%d" % t, frac_tight=0.7)
+        stats = parity.compare(st[:, parity.CONT], nxt[:, parity.CONT], sens, what="live t=%d" % t, frac_tight=0.9, max_exempt=0.1)
         ok = sens < 1e-3
         assert np.array_equal(_np(rew)[ok], o_rew[ok].astype(np.float32))
         assert np.array_equal(_np(done)[ok], o_done[ok])
@@ -353,3 +353,65 @@ def test_rollout_statistics_match_oracle(gxk, oracle):
     calm = (np.abs(ora[:, 20] - 0.04) < 1e-3) & (np.abs(dev[:, 20] - 0.04) < 1e-3) & (ora[:, 50] == 0)
     assert calm.mean() > 0.2
     assert np.median(np.abs(dev[calm, :7] - ora[calm, :7]).max(axis=1)) < 2e-3
+
+
+def test_contact_regime_256_envs(gxk, oracle, parity):
+    """The grasp / contact regime with a fixture that bites: 256 envs under the scripted reach-grasp-lift with per-env
+    jitter (tools/gen_oracle_fixtures.JitteredGrasp), every transition replayed on the device from the oracle's
+    state.  Thresholds are what the kernels achieve, not what they are allowed: >= 90 % of the envs inside the plain
+    5e-4 + 2e-4|x| bound at EVERY step, <= 10 % exempt (sens > 0.05), the allowance of the rest capped at 1e-2, and the
+    rows that are in contact (pad impulses / touch flag) held to the same numbers separately."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_oracle_fixtures import JitteredGrasp
+    E = 256
+    ora = oracle.OraclePnP(E, seed=61)
+    ora.reset()
+    for _ in range(3):
+        ora.step(np.zeros((E, 4)))
+    env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=61, auto_reset=False)
+    pol = JitteredGrasp(E, seed=5)
+    worst_tight, worst_exempt, n_contact, n_contact_tight, n_flag, n_ok = 1.0, 0.0, 0, 0, 0, 0
+    for t in range(pol.horizon):
+        st0 = ora.get_state()
+        a = pol(st0, t)
+        nxt, o_obs, o_ag, o_dg, o_rew, o_done, o_succ, sens = parity.oracle_step_with_sens(ora, st0, a, seed=t)
+        env.set_state(st0)
+        obs, rew, done, info = env.step(torch.tensor(a, dtype=torch.float32))
+        dev = _np(env.get_state()).astype(np.float64)
+        stats = parity.compare(dev[:, parity.CONT], nxt[:, parity.CONT], sens, what="contact regime t=%d" % t, frac_tight=0.9, max_exempt=0.1)
+        worst_tight, worst_exempt = min(worst_tight, stats["frac_tight"]), max(worst_exempt, stats["frac_exempt"])
+        contact = ((np.abs(nxt[:, 42:50]) > 0).any(axis=1) | (nxt[:, 50] > 0)) & (sens <= parity.SENS_EXEMPT)
+        err = np.abs(dev[:, parity.CONT] - nxt[:, parity.CONT])
+        tight = (err <= parity.ATOL + parity.RTOL * np.abs(nxt[:, parity.CONT])).all(axis=1)
+        n_contact += contact.sum()
+        n_contact_tight += (contact & tight).sum()
+        ok = sens < 1e-3
+        assert np.array_equal(_np(rew)[ok], o_rew[ok].astype(np.float32)) and np.array_equal(_np(done)[ok], o_done[ok])
+        n_flag += (dev[ok, 50] == nxt[ok, 50]).sum()
+        n_ok += ok.sum()
+        assert (dev[:, 34:50] >= 0).all()                       # normal impulses never pull
+    lifted = nxt[:, 20] > 0.15
+    print("contact regime (%s): worst frac_tight %.3f, worst frac_exempt %.3f, contact rows %d (%.3f tight), lifted %.2f"
+          % (gxk.family, worst_tight, worst_exempt, n_contact, n_contact_tight / max(n_contact, 1), lifted.mean()))
+    assert n_contact > 1500 and n_contact_tight >= 0.9 * n_contact
+    assert n_flag >= 0.98 * n_ok
+    assert lifted.mean() > 0.4                                   # the script really grasps and lifts in the oracle
+    # free-running device rollout under the same closed-loop script: invariants of the contact phase + the lift rate
+    env.reset()
+    for _ in range(3):
+        env.step(torch.zeros(E, 4))
+    pol = JitteredGrasp(E, seed=5)
+    for t in range(pol.horizon):
+        st = _np(env.get_state()).astype(np.float64)
+        env.step(torch.tensor(pol(st, t), dtype=torch.float32))
+        s = _np(env.get_state())
+        assert np.isfinite(s).all() and (s[:, 34:50] >= 0).all()
+        on_table = (np.abs(s[:, 18]) < 0.7) & (np.abs(s[:, 19]) < 0.45)
+        assert (s[on_table, 20] > 0.02).all()                    # never pressed into the table (half extents 0.025 / 0.04)
+        assert (np.abs(np.linalg.norm(s[:, 21:25], axis=1) - 1) < 1e-5).all()
+    dev_lifted = s[:, 20] > 0.15
+    held = dev_lifted & (s[:, 50] > 0)
+    assert abs(dev_lifted.mean() - lifted.mean()) < 0.08, (dev_lifted.mean(), lifted.mean())
+    assert held.sum() >= 0.9 * dev_lifted.sum()                  # lifted means held between the pads
+    env.close()

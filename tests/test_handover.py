@@ -95,7 +95,7 @@ def test_hostcore_lane_pair_f32_within_tolerance(hostcore, groll, parity):
     sub = slice(0, 10)
     for t in range(1, g["actions"].shape[0], 6):
         st, *_ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=1, seed=2)
-        parity.compare(st[:, CONT], g["states"][t + 1][sub][:, CONT], g["sens"][t][sub], what="handover f32 t=%d" % t, frac_tight=0.5, max_exempt=0.4)
+        parity.compare(st[:, CONT], g["states"][t + 1][sub][:, CONT], g["sens"][t][sub], what="handover f32 t=%d" % t, frac_tight=0.7, max_exempt=0.3)
 
 
 def test_dense_reward_matches_reference_formula(oracle, gref):
@@ -161,7 +161,7 @@ def test_gpu_handover_replays_golden_rollout(groll, parity):
         obs, rew, done, info = env.step(torch.tensor(g["actions"][t], dtype=torch.float32))
         st = env.get_state().cpu().numpy().astype(np.float64)
         sens = g["sens"][t]
-        parity.compare(st[:, CONT], g["states"][t + 1][:, CONT], sens, what="handover gpu t=%d" % t, frac_tight=0.6, max_exempt=0.3)
+        parity.compare(st[:, CONT], g["states"][t + 1][:, CONT], sens, what="handover gpu t=%d" % t, frac_tight=0.75, max_exempt=0.25)   # 24 envs; at t = 30 both arms hold the stick and the script ends
         ok = sens < 1e-3
         np.testing.assert_allclose(obs["observation"].cpu().numpy()[ok], g["obs"][t][ok], atol=3e-3)
         assert np.array_equal(rew.cpu().numpy()[ok], g["rew"][t][ok].astype(np.float32))

@@ -39,6 +39,39 @@ def scripted_actions(ora, phase_len=(8, 6, 8, 6, 8)):
     return np.stack(acts)
 
 
+class JitteredGrasp:
+    """The scripted reach-grasp-lift above as a closed-loop policy on STATES (oracle or device), with per-env jitter
+    of the phase lengths, the approach offset and the descent height, so that a batch covers the contact onset, the
+    closing fingers and the loaded lift at many different phases at once (tests/test_gpu_parity.py contact regime)."""
+
+    def __init__(self, E, seed=0):
+        rng = np.random.default_rng(seed)
+        self.settle = rng.integers(5, 10, E)
+        self.above = self.settle + rng.integers(5, 8, E)
+        self.down = self.above + rng.integers(7, 10, E)
+        self.close = self.down + rng.integers(5, 8, E)
+        self.dxy = rng.uniform(-0.004, 0.004, (E, 2))
+        self.zdown = rng.uniform(0.146, 0.154, E)
+        self.box0 = None
+        self.horizon = int(self.close.max()) + 9
+
+    def __call__(self, st, t):
+        E = st.shape[0]
+        eef = np.stack([O.fk(st[e, :9])[0][7] for e in range(E)])
+        if self.box0 is None:
+            self.box0 = np.zeros((E, 3))
+        latch = t == self.settle
+        self.box0[latch] = st[latch, 18:21]
+        ph = (t >= self.settle).astype(int) + (t >= self.above) + (t >= self.down) + (t >= self.close)
+        z = np.choose(ph, [0.25 * np.ones(E), 0.25 * np.ones(E), self.zdown, self.zdown, 0.35 * np.ones(E)])
+        tgt = np.column_stack([self.box0[:, 0] + self.dxy[:, 0], self.box0[:, 1] + self.dxy[:, 1], z])
+        tgt[ph == 0] = eef[ph == 0]
+        a = np.zeros((E, 4))
+        a[:, :3] = np.clip((tgt - eef) / 0.0625, -1, 1)
+        a[:, 3] = np.where(ph < 3, 1.0, -1.0)
+        return a
+
+
 def record(ora, actions):
     states, outs, sens = [ora.get_state()], [], []
     for t in range(actions.shape[0]):

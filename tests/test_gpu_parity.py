@@ -245,6 +245,35 @@ def test_full_size_properties_65536(gx):
     assert (st[:, 52] == 3).all() | (full[3] != 0).any()
 
 
+def test_full_size_properties_16384(gx):
+    """BASELINE config 3 (16 384 envs on one GPU): same size-independent properties on the one-env-per-lane step
+    kernel below the headline size (256 wavefronts), with the per-step resets on the cooperative kernel"""
+    E = 16384
+    a = [torch.rand(E, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + k)) * 2 - 1 for k in range(4)]
+
+    def run(n, off):
+        env = gx.make("XarmPDPickAndPlace-v0", num_envs=n, seed=23, env_id_offset=off)
+        env.reset()
+        env.set_episode_steps((torch.arange(n, device="cuda") + off) % 50)      # time-limit resets in every call
+        for k in range(4):
+            obs, rew, done, info = env.step(a[k][off:off + n])
+        out = env.get_state().clone(), obs["observation"].clone(), rew.clone(), done.clone()
+        env.close()
+        return out
+    full, again = run(E, 0), run(E, 0)
+    for x, y in zip(full, again):
+        assert torch.equal(x, y)
+    tail = run(E - 12288, 12288)          # a 4 096-env shard steps on k_step_coop: equal within float32, not bitwise
+    st = full[0]
+    assert torch.isfinite(st).all() and float((st[:, 21:25].norm(dim=1) - 1).abs().max()) < 1e-5
+    assert bool((st[:, 34:50] >= 0).all())
+    assert bool(torch.equal(st[12288:, 31:34], tail[0][:, 31:34])) and bool(torch.equal(st[12288:, 52:], tail[0][:, 52:]))   # goals, counters
+    err = (st[12288:, :18] - tail[0][:, :18]).abs().max(dim=1).values
+    assert float(err.median()) < 1e-4
+    ep = st[:, 53]
+    assert int((ep == 2).sum()) >= 4 * E // 50 - 8             # four calls x E / 50 time-limit resets (+ successes)
+
+
 def test_dense_reward_on_grasp_rollout(gxk, oracle, golden_rollout, parity):
     """reward_type='dense' (:166-175): staged reward incl. the contact-flag branches, HIP vs oracle"""
     g = golden_rollout

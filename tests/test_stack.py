@@ -339,3 +339,38 @@ def test_stack_gpu_rollout_statistics_match_oracle(oracle):
     calm = (np.abs(ora[:, 75:93]).max(axis=1) < 1e-6) & (np.abs(dev[:, 75:93]).max(axis=1) < 1e-4)
     assert calm.mean() > 0.2
     assert np.median(np.abs(dev[calm, 0:18] - ora[calm, 0:18]).max(axis=1)) < 2e-3
+
+
+@pytest.mark.gpu
+def test_stack_gpu_full_size_properties_8192():
+    """BASELINE config 4's per-GPU shard (65 536 envs over 8 GPUs = 8 192: 256 wavefronts holding 151 KB of LDS each,
+    one per CU) - size-independent properties: determinism, shard invariance, state invariants, auto-reset."""
+    import torch
+    E = 8192
+    a = [torch.rand(E, 8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(k)) * 2 - 1 for k in range(4)]
+
+    def run(n, off):
+        env = _make(n, seed=9, env_id_offset=off)
+        env.reset()
+        s = env.get_state()
+        s[: n // 4, 134] = 48                                   # a quarter of the shard hits the 50-step limit in call 2
+        env.set_state(s)
+        for k in range(4):
+            obs, rew, done, info = env.step(a[k][off:off + n])
+        out = env.get_state().clone(), obs["observation"].clone(), rew.clone(), done.clone(), env.episode_steps().clone()
+        env.close()
+        return out
+    full, again = run(E, 0), run(E, 0)
+    for x, y in zip(full, again):
+        assert torch.equal(x, y)                                # deterministic, bitwise
+    half = run(E // 2, E // 2)
+    st, steps = full[0], full[4]
+    quarter = E // 4
+    # the second half of the batch carries no manipulated counters in either run: bitwise world-size invariant
+    assert torch.equal(st[E // 2 + E // 8:], half[0][E // 8:]) and torch.equal(full[1][E // 2 + E // 8:], half[1][E // 8:])
+    assert torch.isfinite(st).all()
+    q = st[:, 63:75].reshape(E, 3, 4)
+    assert float((q.norm(dim=2) - 1).abs().max()) < 1e-5                              # cube quaternions
+    assert bool((st[:, 102:134] >= 0).all())                                          # normal impulses never pull
+    assert bool((steps[:quarter] == 2).all()) and bool((steps[quarter:] == 4).all())  # reset inside call 2, then 2 more steps
+    assert bool(((full[2] == 0) | (full[2] == -1)).all())                             # sparse reward (:124-127)

@@ -204,12 +204,21 @@ def test_gpu_reach_4096_episode_and_registry(gref):
 
 
 @pytest.mark.gpu
-def test_gpu_a2c_learns_reach():
+def test_gpu_a2c_learns_reach(tmp_path):
     """the reference's consumer of the env boundary (benchmark/train.py: VecNormalize + A2C) on the batched env:
-    a few hundred on-device A2C updates must improve the dense Reach reward markedly"""
+    a few hundred on-device A2C updates must improve the dense Reach reward markedly; the run leaves the artefacts of
+    the reference's script (Monitor CSV :74, best model :16-47, VecNormalize statistics :107-108)"""
+    import os
     from gym_xarm_amd.train import train
     model, venv, hist = train("XarmReach-v0", num_envs=2048, updates=300, config={"reward_type": "dense", "GUI": False},
-                              log_every=50, quiet=True)
+                              log_every=50, quiet=True, log_dir=str(tmp_path), check_freq=250)
     first, last = hist[0]["mean_raw_reward"], hist[-1]["mean_raw_reward"]
     assert last > first + 0.03, (first, last, hist)          # mean -distance to the goal shrinks by > 3 cm
     assert hist[-1]["env_steps_per_sec"] > 2e5
+    assert {"0.monitor.csv", "best_model.safetensors", "vec_normalize.safetensors"} <= set(os.listdir(str(tmp_path)))
+    rows = open(os.path.join(str(tmp_path), "0.monitor.csv")).read().strip().split("\n")
+    assert rows[1] == "r,l,t" and len(rows) - 2 == venv.monitor.n == 2048 * (1500 // 25)       # every 25-step episode logged
+    r = np.array([float(x.split(",")[0]) for x in rows[2:]])
+    l = np.array([int(x.split(",")[1]) for x in rows[2:]])
+    assert (l == 25).all() and r[-2048:].mean() > r[:2048].mean()                                 # returns improve
+    assert venv.callback.saves >= 2 and venv.callback.best_mean_reward > r[:2048].mean()

@@ -55,6 +55,15 @@ WORKLOAD_NAMES = {
 SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15}   # internal substeps (Handover: 15 ticks of one substep)
 
 
+def reference_availability():
+    """the reference's arithmetic lives in PyBullet; report whether this box could run it side by side"""
+    try:
+        import pybullet  # noqa: F401
+    except Exception as e:   # ModuleNotFoundError on every box of this project so far
+        return "unavailable (pybullet not importable: %s)" % type(e).__name__
+    return "pybullet importable - side-by-side harness: tools/pybullet_harness.py (not run by bench.py)"
+
+
 def cpu_baseline(workload="pnp"):
     """The CPU oracle (a restatement = kind "port"; PyBullet itself is absent) on the host cores:
     every thread steps its own shard through ctypes (the GIL is released inside the C call)."""
@@ -86,25 +95,25 @@ def cpu_baseline(workload="pnp"):
     return {"value": n / wall_steps, "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps of %s on the CPU oracle (float64, gcc -O2), %d threads, %.1f s"
                       % (cores * sample_envs_per_thread, steps, env_id, cores, wall + wall_steps),
-            "reference": "unavailable (pybullet not importable)"}
+            "reference": reference_availability()}
 
 
-def timed_window(env, ring, first, steps, world, dev, dist, D, torch):
+def timed_window(env, ring, first, steps, world, dev, dist, D, torch, sync):
     """time exactly `steps` calls of env.step between two barriers + synchronize; returns max-over-ranks seconds,
     episodes finished, and the HIP-event averages of the step kernel and of the reset kernels (ms per call)"""
     env.timing_enable(True)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     n_done = torch.zeros((), device=dev)
     for i in range(steps):
         obs, rew, done, info = env.step(ring[(first + i) % 64])
         n_done += done.sum()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     kstep_ms_total, launches = env.timing_read()
     reset_ms_total, _ = env.timing_read_reset()
@@ -138,15 +147,29 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
-    # rehearsal hooks for a 1-GPU box: XARM_BENCH_DEVICE pins every rank to one device, XARM_BENCH_BACKEND=gloo
-    # replaces RCCL (two ranks cannot share a device under RCCL); the driver's real runs use neither
-    dev_index = int(os.environ.get("XARM_BENCH_DEVICE", local_rank))
+    # rehearsal hooks (the driver's real runs use none of them): XARM_BENCH_DEVICE pins every rank to one device of a
+    # 1-GPU box, or to "cpu" together with XARM_BENCH_ENV_FACTORY=module:function (a stand-in env: the CPU test of this
+    # file's rank plumbing, tests/test_distributed.py); XARM_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a
+    # device under RCCL)
+    dev_spec = os.environ.get("XARM_BENCH_DEVICE", str(local_rank))
     backend = os.environ.get("XARM_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    on_cpu = dev_spec == "cpu"
+    if on_cpu:
+        dev = torch.device("cpu")
+        if not os.environ.get("XARM_BENCH_ENV_FACTORY"):
+            raise SystemExit("XARM_BENCH_DEVICE=cpu needs XARM_BENCH_ENV_FACTORY (the product has no CPU path)")
+    else:
+        torch.cuda.set_device(int(dev_spec))
+        dev = torch.device("cuda", int(dev_spec))
+    sync = (lambda: None) if on_cpu else torch.cuda.synchronize
+    make = gym_xarm_amd.make
+    if os.environ.get("XARM_BENCH_ENV_FACTORY"):
+        import importlib
+        mod, _, fn = os.environ["XARM_BENCH_ENV_FACTORY"].partition(":")
+        make = getattr(importlib.import_module(mod), fn)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+        if backend == "nccl" and not on_cpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -158,7 +181,7 @@ def main():
         E, offset = hi - lo, lo
     else:
         E, offset = n_cfg, rank * n_cfg
-    env = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config)
+    env = make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
@@ -172,10 +195,10 @@ def main():
         # launch: round 1 timed the first `done.sum()` inside the window, 50-80 ms of module loading)
         obs, rew, done, info = env.step(ring[i % 64])
         n_done += done.sum()
-    torch.cuda.synchronize()
+    sync()
     windows = []
     for r in range(max(1, args.repeats)):
-        windows.append(timed_window(env, ring, args.warmup + r * args.steps, args.steps, world, dev, dist, D, torch))
+        windows.append(timed_window(env, ring, args.warmup + r * args.steps, args.steps, world, dev, dist, D, torch, sync))
     total_envs = int(D.sum_over_ranks(E, device=dev))
     order = sorted(range(len(windows)), key=lambda k: windows[k][0])
     dt, resets, kstep_ms, reset_ms, launches = windows[order[len(order) // 2]]     # the median window
@@ -185,25 +208,25 @@ def main():
     lazy = None
     if args.workload == "pnp" and not args.no_lazy:
         env.close()
-        lenv = gym_xarm_amd.make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config, auto_reset="lazy")
+        lenv = make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config, auto_reset="lazy")
         lenv.reset()
         useful = torch.zeros((), device=dev)
         for i in range(args.warmup):
             _, _, _, linfo = lenv.step(ring[i % 64])
             useful += (~linfo["resetting"]).sum()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         useful = torch.zeros((), device=dev)
         for i in range(args.steps):
             _, _, _, linfo = lenv.step(ring[(args.warmup + i) % 64])
             useful += (~linfo["resetting"]).sum()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         ldt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
         luse = D.sum_over_ranks(float(useful.item()), device=dev)
         lazy = {"value": luse / ldt, "unit": "useful env steps/s (reset ticks excluded)", "ms_per_step": ldt / args.steps * 1e3,

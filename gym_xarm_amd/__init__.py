@@ -52,3 +52,30 @@ for _id in ("XarmHandover-v0", "XarmPDHandover-v0"):
 # config 4 names it XarmPDStackTower-v0
 for _id in ("XarmStackTower-v0", "XarmPDStackTower-v0"):
     register(_id, "gym_xarm_amd.envs:XarmStackTowerEnv", 50, "gym_xarm_amd.vec_env:XarmStackTowerVecEnv")
+
+
+def register_with_gym():
+    """Mirror the registry into a real `gym` / `gymnasium` when one is importable, so that `gym.make('Xarm*-v0',
+    config=...)` resolves to these classes exactly as the reference's `gym_xarm/__init__.py:6-22` arranges it
+    (entry_point + max_episode_steps).  Neither package is installed in the build image: then this is a no-op and
+    `gym_xarm_amd.make` is the registry.  Returns the names of the packages that took the registrations."""
+    took = []
+    for name in ("gym", "gymnasium"):
+        try:
+            mod = __import__(name)
+            reg = __import__(name + ".envs.registration", fromlist=["register"])
+        except Exception:
+            continue
+        known = getattr(getattr(mod.envs, "registry", None), "keys", lambda: [])()
+        for env_id, spec_ in _REGISTRY.items():
+            if env_id in known:
+                continue
+            try:
+                reg.register(id=env_id, entry_point=spec_["entry_point"], max_episode_steps=spec_["max_episode_steps"])
+            except Exception:
+                continue
+        took.append(name)
+    return took
+
+
+_GYM_BACKENDS = register_with_gym()

@@ -23,27 +23,55 @@ def env_from_torchrun():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+class Rank0Gather:
+    """Observation gather to rank 0 for a single learner: per-rank rows [E_r, d] -> [sum E_r, d] on rank 0, ordered by
+    global env id.  The shard sizes are exchanged ONCE, when the object is built (one small all_gather); every call
+    after that is one send per rank into receive buffers rank 0 keeps, with no pickling and no host synchronisation
+    beyond the transfers themselves.  Direct sends rather than a ring all-gather: on MI355X rank 0 has 7 inbound xGMI
+    links that work in parallel, a ring would be per-link bound."""
+
+    def __init__(self, rows, row_shape, dtype, device=None, total_envs=None, group=None):
+        self.group, self.row_shape, self.dtype = group, tuple(row_shape), dtype
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rows = int(rows)
+        if not self.active:
+            return
+        self.ws, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        cdev = _coll_device(device)
+        mine = torch.tensor([self.rows], dtype=torch.int64, device=cdev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(self.ws)]
+        dist.all_gather(sizes, mine, group=group)
+        self.sizes = [int(t.item()) for t in sizes]
+        if total_envs is not None and sum(self.sizes) != int(total_envs):
+            raise ValueError("shards hold %d envs, expected %d" % (sum(self.sizes), total_envs))
+        self.out = None
+        if self.rank == 0:
+            self.out = torch.empty((sum(self.sizes),) + self.row_shape, dtype=dtype, device=device)
+            offs = [0]
+            for n in self.sizes:
+                offs.append(offs[-1] + n)
+            self.views = [self.out[offs[r]:offs[r + 1]] for r in range(self.ws)]
+
+    def __call__(self, x):
+        """x: this rank's rows.  Returns the gathered tensor on rank 0 (a buffer reused by the next call), None elsewhere."""
+        if not self.active:
+            return x
+        if tuple(x.shape) != (self.rows,) + self.row_shape:
+            raise ValueError("expected rows of shape %s, got %s" % ((self.rows,) + self.row_shape, tuple(x.shape)))
+        if self.rank == 0:
+            self.views[0].copy_(x)
+            reqs = [dist.irecv(self.views[r], src=r, group=self.group) for r in range(1, self.ws)]
+            for r in reqs:
+                r.wait()
+            return self.out
+        dist.send(x.contiguous(), dst=0, group=self.group)
+        return None
+
+
 def gather_to_rank0(x, total_envs=None, group=None):
-    """Gather per-rank rows [E_r, d] to rank 0 -> [sum E_r, d] (rows ordered by global env id).
-    Direct gather (every rank sends once to rank 0) rather than a ring all-gather: on MI355X rank 0
-    has 7 inbound xGMI links that work in parallel, a ring would be per-link bound."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return x
-    ws, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [None] * ws
-    dist.all_gather_object(sizes, int(x.shape[0]), group=group)
-    if rank == 0:
-        bufs = [torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for n in sizes]
-        bufs[0].copy_(x)
-        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, ws)]
-        for r in reqs:
-            r.wait()
-        out = torch.cat(bufs, dim=0)
-        if total_envs is not None:
-            assert out.shape[0] == total_envs
-        return out
-    dist.send(x.contiguous(), dst=0, group=group)
-    return None
+    """One-off form of Rank0Gather (sizes exchanged in this call); use the class for a gather per step."""
+    g = Rank0Gather(x.shape[0], x.shape[1:], x.dtype, device=x.device if x.is_cuda else None, total_envs=total_envs, group=group)
+    return g(x)
 
 
 def _coll_device(device):

@@ -46,6 +46,13 @@ def _worker(rank, ws, port, total, q):
     a = np.random.default_rng(5).uniform(-1, 1, size=(total, 4))[lo:hi]
     obs, ag, dg, rew, done, succ = env.step(a)
     g = gather_to_rank0(torch.from_numpy(obs), total_envs=total)
+    # the per-step form: sizes exchanged once at construction, buffers reused by every call
+    from gym_xarm_amd.distributed import Rank0Gather
+    gat = Rank0Gather(hi - lo, obs.shape[1:], torch.float64, total_envs=total)
+    for k in range(3):
+        gk = gat(torch.from_numpy(obs) + k)
+        if rank == 0:
+            assert torch.equal(gk, g + k)
     t = max_over_ranks(1.0 + rank)
     n = sum_over_ranks(hi - lo)
     if rank == 0:
@@ -74,3 +81,68 @@ def test_two_rank_shards_equal_single_process():
     obs = env.step(a)[0]
     assert np.array_equal(gathered, obs)          # bitwise: sharding does not change any env
     assert tmax == 2.0 and n == total
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_rank_plumbing_two_ranks_gloo(tmp_path, scaling):
+    """bench.py under torch.distributed.run with two ranks on CPU (gloo, a stand-in env): the launch line the driver
+    uses, the barrier / max-over-ranks timing, the env-id sharding of both scaling modes and the one JSON line of rank 0"""
+    import json
+    import subprocess
+    log = str(tmp_path / "stub")
+    env = dict(os.environ, XARM_BENCH_DEVICE="cpu", XARM_BENCH_BACKEND="gloo", XARM_BENCH_ENV_FACTORY="bench_stub:make",
+               XARM_BENCH_STUB_LOG=log, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
+           "--envs-per-gpu", "101", "--scaling", scaling, "--repeats", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 3 and d["scaling"] == scaling and d["higher_is_better"] is True
+    shards = [[json.loads(l) for l in open(log + ".%d" % r)] for r in range(2)]
+    if scaling == "weak":
+        assert d["config"]["total_envs"] == 202 and [s[0]["num_envs"] for s in shards] == [101, 101]
+        assert [s[0]["env_id_offset"] for s in shards] == [0, 101]
+    else:
+        assert d["config"]["total_envs"] == 101 and [s[0]["num_envs"] for s in shards] == [51, 50]      # shard_range
+        assert [s[0]["env_id_offset"] for s in shards] == [0, 51]
+    assert all(s[1]["auto_reset"] == "lazy" for s in shards)                                             # the lazy leg ran too
+    assert abs(d["value"] - d["config"]["total_envs"] * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
+    assert len(d["repeats"]["env_steps_per_sec"]) == 2 and d["repeats"]["min"] <= d["value"] <= d["repeats"]["max"]
+    assert d["roofline"]["kernels"]["reset"]["avg_ms"] == 0.25 and abs(d["roofline"]["kernel_avg_ms"] - 0.75) < 1e-9
+    # desynchronised phases, 10-step episodes: each env finishes once per 10 steps
+    assert abs(d["config"]["resets_per_step"] - d["config"]["total_envs"] / 10) <= d["config"]["total_envs"] / 10 * 0.5 + 2
+
+
+def test_rank0_gather_reuses_sizes(tmp_path):
+    """Rank0Gather exchanges the shard sizes once; without a process group it is the identity"""
+    from gym_xarm_amd.distributed import Rank0Gather
+    g = Rank0Gather(5, (3,), torch.float32)
+    x = torch.randn(5, 3)
+    assert g(x) is x and not g.active
+
+
+def test_register_with_gym_mirrors_registry(monkeypatch):
+    """with a `gym` importable, the reference's ids are registered there with its entry_point / max_episode_steps
+    convention (gym_xarm/__init__.py:6-22); without one (this image) the hook is a no-op"""
+    import types
+    import gym_xarm_amd
+    assert gym_xarm_amd._GYM_BACKENDS == [] or set(gym_xarm_amd._GYM_BACKENDS) <= {"gym", "gymnasium"}
+    calls = []
+    gym = types.ModuleType("gym")
+    gym.envs = types.ModuleType("gym.envs")
+    gym.envs.registry = {}
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda id, entry_point, max_episode_steps: calls.append((id, entry_point, max_episode_steps))
+    gym.envs.registration = reg
+    for name, mod in (("gym", gym), ("gym.envs", gym.envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setitem(sys.modules, "gymnasium", None)        # import of gymnasium fails
+    assert gym_xarm_amd.register_with_gym() == ["gym"]
+    got = {c[0]: c for c in calls}
+    assert got["XarmReach-v0"][1:] == ("gym_xarm_amd.envs:XarmReachEnv", 25)
+    assert got["XarmHandover-v0"][1:] == ("gym_xarm_amd.envs:XarmHandover", 100)
+    assert got["XarmPickAndPlace-v1"][1:] == ("gym_xarm_amd.envs:XarmPickAndPlace", 50)
+    assert set(got) == set(gym_xarm_amd.registered_ids())

@@ -40,8 +40,13 @@
 #define XARM_LDS_FENCE() asm volatile("" ::: "memory")
 #else
 #define XARM_HD inline
-// host build: always run the masked path so that the predication logic itself is tested
+// host build: always run the masked path so that the predication logic itself is tested (tools/flopcount defines
+// XARM_HOST_ANY_PER_ENV to follow the per-environment predicate instead: the algorithmic operation count)
+#ifdef XARM_HOST_ANY_PER_ENV
+#define XARM_ANY(p) (p)
+#else
 #define XARM_ANY(p) (true)
+#endif
 #define XARM_ANY_X(p) (p)
 #define XARM_LDS_FENCE() ((void)0)
 #endif

@@ -87,3 +87,38 @@ def test_scene_constants_match_env_file():
     assert "gearRatio=-1, erp=0.1, maxForce=50" in src
     assert JS["solver"]["gear_erp"] == 0.1 and JS["solver"]["gear_max_force"] == 50.0
     assert "lateralFriction = 100" in src and JS["solver"]["mu_finger_grasp"] == 100.0
+
+
+def test_primitives_urdf_round_trips_the_model_table():
+    """tools/emit_primitives_urdf.py: the URDF a PyBullet side-by-side run would load carries exactly the model table's
+    joints, masses, inertias and the build's collision primitives"""
+    import json
+    import sys
+    import xml.etree.ElementTree as ET
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from emit_primitives_urdf import emit
+    js = json.load(open(os.path.join(ROOT, "gym_xarm_amd", "model", "xarm7_pd.json")))
+    root = ET.fromstring(emit(js))
+    links = {l.attrib["name"]: l for l in root.findall("link")}
+    joints = {j.find("child").attrib["link"]: j for j in root.findall("joint")}
+    assert len(links) == len(js["links"]) + 1 and len(joints) == len(js["links"])
+    for i, l in enumerate(js["links"]):
+        e, j = links[l["name"]], joints[l["name"]]
+        assert float(e.find("inertial/mass").attrib["value"]) == l["mass"]
+        assert [float(x) for x in e.find("inertial/origin").attrib["xyz"].split()] == [float(x) for x in l["com"]]
+        assert float(e.find("inertial/inertia").attrib["ixx"]) == l["inertia"][0] and float(e.find("inertial/inertia").attrib["izz"]) == l["inertia"][5]
+        assert j.attrib["type"] == l["joint"]
+        assert [float(x) for x in j.find("origin").attrib["xyz"].split()] == [float(x) for x in l["origin_xyz"]]
+        if l["joint"] != "fixed":
+            assert [float(x) for x in j.find("axis").attrib["xyz"].split()] == [float(x) for x in l["axis"]]
+            assert float(j.find("limit").attrib["lower"]) == l["lower"] and float(j.find("dynamics").attrib["damping"]) == l["damping"]
+        n_col = len(e.findall("collision"))
+        assert n_col == (len(js["pads"]["centers_left"]) if i in js["finger_links"] else 0)     # only the pad spheres collide
+
+
+def test_pybullet_harness_reports_unavailable_cleanly():
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pybullet_harness.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    assert out.stdout.startswith("reference: unavailable (pybullet not importable") or out.stdout.startswith("reference: pybullet")

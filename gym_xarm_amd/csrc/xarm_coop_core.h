@@ -116,6 +116,29 @@ template <typename T> XARM_HD T lv_allsum(LV<T> x) {
 }
 #endif
 template <int L, typename T> XARM_HD T lv_get(LV<T> x) { return lv_bcast<L>(x).v[0]; }
+// y[l] = sum of x[k] over the lanes k >= l of the row (Hillis-Steele with DPP row_shl 1, 2, 4, 8; lanes shifted in
+// from beyond the row read 0)
+#if defined(__HIPCC__) && !defined(XARM_HOST_BUILD)
+XARM_HD LV<float> lv_suffix_sum(LV<float> x) {
+    XC_NO_CONTRACT
+    float s = x.v[0];
+    s += dpp<0x101>(s);
+    s += dpp<0x102>(s);
+    s += dpp<0x104>(s);
+    s += dpp<0x108>(s);
+    LV<float> r; r.v[0] = s; return r;
+}
+#else
+template <typename T> XARM_HD LV<T> lv_suffix_sum(LV<T> x) {
+    T a[GL], b[GL];
+    for (int i = 0; i < GL; i++) a[i] = x.v[i];
+    for (int sh = 1; sh < GL; sh *= 2) {
+        for (int i = 0; i < GL; i++) b[i] = a[i] + (i + sh < GL ? a[i + sh] : (T)0);
+        for (int i = 0; i < GL; i++) a[i] = b[i];
+    }
+    LV<T> r; for (int i = 0; i < GL; i++) r.v[i] = a[i]; return r;
+}
+#endif
 
 // two values per lane that are always updated together: the table row and the single-joint row a lane owns (slots 0
 // and 1 are never coupled to each other, so row i of both can be processed in ONE step).  Device: an aligned VGPR pair,
@@ -520,14 +543,218 @@ template <typename T, bool PAD, bool LA> XARM_HD void apply_warm_start(Sweep<T> 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Arm dynamics with the per-body work dealt to the lanes of the row (lane b = body b: links 1-7, the two fingers).
+// xk::arm_dynamics spends most of its instructions on nine rigid-body inertias about the world origin, their bias
+// forces and the composite-rigid-body products; here the kinematic chain (frames, velocities, accelerations: a
+// serial recursion) is still walked by every lane, each lane captures the frame of ITS body on the way, forms that
+// body's inertia and bias force, a DPP suffix scan over the lanes turns them into the composites of the subtree, and
+// lane j computes row j of the joint-space inertia.  The rows are then broadcast and the 9x9 factorisation runs
+// redundantly as before.  Same quantities as xk::arm_dynamics (summation order of the composites differs).
+template <typename T> struct ArmLane { LV<T> mass, com[3], inertia[6], damping; };   // per-lane body constants
+template <typename T> XARM_HD ArmLane<T> arm_lane_consts(const Grp &G) {
+    ArmLane<T> C;
+    XC_LANES {
+        const int l = lane_of(G, i_);
+        T m = (T)0, dmp = (T)0, c[3] = {(T)0, (T)0, (T)0}, in[6] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+        for (int b = 0; b < 9; b++) {
+            m = l == b ? (T)xm::MASS[b] : m;
+            dmp = l == b ? (T)xm::DAMPING[b] : dmp;
+#pragma unroll
+            for (int k = 0; k < 3; k++) c[k] = l == b ? (T)xm::COM[b][k] : c[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) in[k] = l == b ? (T)xm::INERTIA[b][k] : in[k];
+        }
+        C.mass.v[i_] = m; C.damping.v[i_] = dmp;
+#pragma unroll
+        for (int k = 0; k < 3; k++) C.com[k].v[i_] = c[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) C.inertia[k].v[i_] = in[k];
+    }
+    return C;
+}
+
+template <typename T, typename Lds>
+XARM_HD void arm_dynamics_coop(const Grp &G, const ArmLane<T> &C, const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, xk::ArmDyn<T> &A) {
+    using xk::SV; using xk::RBI; using xk::Frame;
+    // ---- the chain, walked by every lane; lane i captures body i's frame / spatial velocity / acceleration / joint rate
+    SV<T> S[7];
+    Frame<T> f = xk::frame_identity<T>();
+    SV<T> vel, acc;
+    vel.w = mk<T>(0, 0, 0); vel.v = mk<T>(0, 0, 0);
+    acc.w = mk<T>(0, 0, 0); acc.v = mk<T>(0, 0, (T)xm::GRAVITY);
+    LV<T> cap[24], capqd = lv_fill((T)0);
+#pragma unroll
+    for (int k = 0; k < 24; k++) cap[k] = lv_fill((T)0);
+#define XC_CAPTURE(i, fr, vv, aa, qdv)                                                                       \
+    {                                                                                                        \
+        const T vals[24] = {fr.c0.x, fr.c0.y, fr.c0.z, fr.c1.x, fr.c1.y, fr.c1.z, fr.c2.x, fr.c2.y, fr.c2.z, fr.o.x, fr.o.y, fr.o.z, \
+                            vv.w.x, vv.w.y, vv.w.z, vv.v.x, vv.v.y, vv.v.z, aa.w.x, aa.w.y, aa.w.z, aa.v.x, aa.v.y, aa.v.z}; \
+        _Pragma("unroll") for (int k = 0; k < 24; k++) lv_commit<i>(G, cap[k], lv_fill(vals[k]));            \
+        lv_commit<i>(G, capqd, lv_fill(qdv));                                                                \
+    }
+#define XC_CHAIN(i)                                                                                          \
+    {                                                                                                        \
+        xk::fk_advance(f, i, q_in[i]);                                                                       \
+        S[i].w = f.c2;                                                                                       \
+        S[i].v = cross(f.o, f.c2);                                                                           \
+        const T qd = qd_in[i];                                                                               \
+        acc.w = acc.w + cross(vel.w, S[i].w) * qd;                                                           \
+        acc.v = acc.v + (cross(vel.w, S[i].v) + cross(vel.v, S[i].w)) * qd;                                  \
+        vel.w = vel.w + S[i].w * qd;                                                                         \
+        vel.v = vel.v + S[i].v * qd;                                                                         \
+        XC_CAPTURE(i, f, vel, acc, qd)                                                                       \
+    }
+    XC_CHAIN(0) XC_CHAIN(1) XC_CHAIN(2) XC_CHAIN(3) XC_CHAIN(4) XC_CHAIN(5) XC_CHAIN(6)
+#undef XC_CHAIN
+    const V3<T> hc0 = f.c0, hc1 = f.c1, hc2 = f.c2, ho = f.o;
+    A.hc0 = hc0; A.hc1 = hc1; A.hc2 = hc2;
+    // fingers slide along +/- hand y: frame = hand axes at the finger origin, prismatic velocity / acceleration terms
+#define XC_FINGER(k)                                                                                         \
+    {                                                                                                        \
+        const T sg = k == 0 ? (T)1 : (T)-1;                                                                  \
+        const V3<T> af = hc1 * sg;                                                                           \
+        A.fo[k] = ho + hc2 * (T)xm::FINGER_Z + af * q_in[7 + k];                                             \
+        const T qd = qd_in[7 + k];                                                                           \
+        SV<T> v = vel, a = acc;                                                                              \
+        a.v = a.v + cross(vel.w, af) * qd;                                                                   \
+        v.v = v.v + af * qd;                                                                                 \
+        Frame<T> ff; ff.c0 = hc0; ff.c1 = hc1; ff.c2 = hc2; ff.o = A.fo[k];                                  \
+        XC_CAPTURE(7 + k, ff, v, a, qd)                                                                      \
+    }
+    XC_FINGER(0) XC_FINGER(1)
+#undef XC_FINGER
+#undef XC_CAPTURE
+    // ---- per lane: inertia of the lane's body about the world origin, bias force, then composites by suffix scan
+    LV<T> body[16], comp[16], Mrow[9], taul;
+    XC_LANES {
+        const int l = lane_of(G, i_);
+        const V3<T> c0 = mk<T>(cap[0].v[i_], cap[1].v[i_], cap[2].v[i_]), c1 = mk<T>(cap[3].v[i_], cap[4].v[i_], cap[5].v[i_]),
+                    c2 = mk<T>(cap[6].v[i_], cap[7].v[i_], cap[8].v[i_]), o = mk<T>(cap[9].v[i_], cap[10].v[i_], cap[11].v[i_]);
+        SV<T> v, a;
+        v.w = mk<T>(cap[12].v[i_], cap[13].v[i_], cap[14].v[i_]); v.v = mk<T>(cap[15].v[i_], cap[16].v[i_], cap[17].v[i_]);
+        a.w = mk<T>(cap[18].v[i_], cap[19].v[i_], cap[20].v[i_]); a.v = mk<T>(cap[21].v[i_], cap[22].v[i_], cap[23].v[i_]);
+        const T m = C.mass.v[i_];
+        const V3<T> c = o + c0 * C.com[0].v[i_] + c1 * C.com[1].v[i_] + c2 * C.com[2].v[i_];
+        const T ixx = C.inertia[0].v[i_], ixy = C.inertia[1].v[i_], ixz = C.inertia[2].v[i_], iyy = C.inertia[3].v[i_],
+                iyz = C.inertia[4].v[i_], izz = C.inertia[5].v[i_];
+        const V3<T> m0 = c0 * ixx + c1 * ixy + c2 * ixz, m1 = c0 * ixy + c1 * iyy + c2 * iyz, m2 = c0 * ixz + c1 * iyz + c2 * izz;
+        const T cc = dot(c, c);
+        RBI<T> I;
+        I.m = m;
+        I.h = c * m;
+        I.I[0] = m0.x * c0.x + m1.x * c1.x + m2.x * c2.x + m * (cc - c.x * c.x);
+        I.I[1] = m0.x * c0.y + m1.x * c1.y + m2.x * c2.y - m * c.x * c.y;
+        I.I[2] = m0.x * c0.z + m1.x * c1.z + m2.x * c2.z - m * c.x * c.z;
+        I.I[3] = m0.y * c0.y + m1.y * c1.y + m2.y * c2.y + m * (cc - c.y * c.y);
+        I.I[4] = m0.y * c0.z + m1.y * c1.z + m2.y * c2.z - m * c.y * c.z;
+        I.I[5] = m0.z * c0.z + m1.z * c1.z + m2.z * c2.z + m * (cc - c.z * c.z);
+        const SV<T> Iv = xk::rbi_mul(I, v), Ia = xk::rbi_mul(I, a);
+        SV<T> fbias;
+        fbias.w = Ia.w + cross(v.w, Iv.w) + cross(v.v, Iv.v);
+        fbias.v = Ia.v + cross(v.w, Iv.v);
+        const T vals[16] = {I.m, I.h.x, I.h.y, I.h.z, I.I[0], I.I[1], I.I[2], I.I[3], I.I[4], I.I[5],
+                            fbias.w.x, fbias.w.y, fbias.w.z, fbias.v.x, fbias.v.y, fbias.v.z};
+#pragma unroll
+        for (int k = 0; k < 16; k++) body[k].v[i_] = l < 9 ? vals[k] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) comp[k] = lv_suffix_sum(body[k]);
+    // ---- per lane: row l of the joint-space inertia and the bias torque (arm lanes: composite of the subtree, revolute
+    // axis; finger lanes: their own body, prismatic axis along +/- hand y)
+    XC_LANES {
+        const int l = lane_of(G, i_);
+        const bool fin = l >= 7;
+        RBI<T> Ic;
+        SV<T> fc, Sl;
+        const LV<T> *src = comp;
+        Ic.m = fin ? body[0].v[i_] : src[0].v[i_];
+        Ic.h = mk<T>(fin ? body[1].v[i_] : src[1].v[i_], fin ? body[2].v[i_] : src[2].v[i_], fin ? body[3].v[i_] : src[3].v[i_]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) Ic.I[k] = fin ? body[4 + k].v[i_] : src[4 + k].v[i_];
+        fc.w = mk<T>(fin ? body[10].v[i_] : src[10].v[i_], fin ? body[11].v[i_] : src[11].v[i_], fin ? body[12].v[i_] : src[12].v[i_]);
+        fc.v = mk<T>(fin ? body[13].v[i_] : src[13].v[i_], fin ? body[14].v[i_] : src[14].v[i_], fin ? body[15].v[i_] : src[15].v[i_]);
+        const V3<T> c1 = mk<T>(cap[3].v[i_], cap[4].v[i_], cap[5].v[i_]), c2 = mk<T>(cap[6].v[i_], cap[7].v[i_], cap[8].v[i_]),
+                    o = mk<T>(cap[9].v[i_], cap[10].v[i_], cap[11].v[i_]);
+        const V3<T> ax = c1 * (l == 8 ? (T)-1 : (T)1);                          // finger slide direction
+        Sl.w = fin ? mk<T>(0, 0, 0) : c2;
+        Sl.v = fin ? ax : cross(o, c2);
+        const SV<T> F = xk::rbi_mul(Ic, Sl);
+#pragma unroll
+        for (int i = 0; i < 7; i++) Mrow[i].v[i_] = xk::sdot(S[i], F);
+        Mrow[7].v[i_] = l == 7 ? dot(ax, F.v) : (T)0;                           // finger 2 is not carried by finger 1: M[8][7] = 0
+        Mrow[8].v[i_] = l == 8 ? dot(ax, F.v) : (T)0;
+        taul.v[i_] = -xk::sdot(Sl, fc) - C.damping.v[i_] * capqd.v[i_];
+    }
+    // ---- rows and torques to every lane, then the factorisation as in xk::arm_dynamics
+    T M[45], tau[9];
+#define XC_ROW(r)                                                                                            \
+    {                                                                                                        \
+        _Pragma("unroll") for (int c = 0; c <= r; c++) M[tri(r, c)] = lv_get<r>(Mrow[c]);                    \
+        tau[r] = lv_get<r>(taul);                                                                            \
+    }
+    XC_ROW(0) XC_ROW(1) XC_ROW(2) XC_ROW(3) XC_ROW(4) XC_ROW(5) XC_ROW(6) XC_ROW(7) XC_ROW(8)
+#undef XC_ROW
+    T (&Minv)[45] = A.Minv;
+    {
+        T rd[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+#pragma unroll
+            for (int r = c; r < 9; r++) {
+                T s = M[tri(r, c)];
+#pragma unroll
+                for (int k = 0; k < c; k++) s -= M[tri(r, k)] * M[tri(c, k)];
+                if (r == c) { M[tri(c, c)] = xsqrt(s); rd[c] = (T)1 / M[tri(c, c)]; }
+                else M[tri(r, c)] = s * rd[c];
+            }
+        }
+        T Li[45];
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            Li[tri(c, c)] = rd[c];
+#pragma unroll
+            for (int r = c + 1; r < 9; r++) {
+                T s = (T)0;
+#pragma unroll
+                for (int k = c; k < r; k++) s -= M[tri(r, k)] * Li[tri(k, c)];
+                Li[tri(r, c)] = s * rd[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++) {
+                T s = (T)0;
+#pragma unroll
+                for (int k = r; k < 9; k++) s += Li[tri(k, r)] * Li[tri(k, c)];
+                Minv[tri(r, c)] = s;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        T s = (T)0;
+#pragma unroll
+        for (int c = 0; c < 9; c++) s += Minv[symi(r, c)] * tau[c];
+        A.dq[r] = qd_in[r] + dt * s;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        lds[LDS_S + i * 6 + 0] = S[i].w.x; lds[LDS_S + i * 6 + 1] = S[i].w.y; lds[LDS_S + i * 6 + 2] = S[i].w.z;
+        lds[LDS_S + i * 6 + 3] = S[i].v.x; lds[LDS_S + i * 6 + 4] = S[i].v.y; lds[LDS_S + i * 6 + 5] = S[i].v.z;
+    }
+    XARM_LDS_FENCE();
+}
+
+// ---------------------------------------------------------------------------------------------
 // collision + row constants of a substep: same arithmetic as the first half of xk::substep, minus the
 // operational-space K blocks (the Delassus rows replace them)
 template <typename T, typename Lds>
-XARM_HD void substep_setup(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, Setup<T> &S) {
+XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, Setup<T> &S) {
     using Scene = xk::PnpScene;
     const T idt = (T)1 / dt;
     xk::ArmDyn<T> AD;
-    xk::arm_dynamics<T, Lds, Scene, false>(st.q, st.qd, dt, lds, 0, AD);
+    arm_dynamics_coop<T, Lds>(G, C, st.q, st.qd, dt, lds, AD);
 #pragma unroll
     for (int k = 0; k < 45; k++) S.Minv[k] = AD.Minv[k];
 #pragma unroll
@@ -771,9 +998,9 @@ XARM_HD void solve(const Grp &G, const Setup<T> &S, Lds lds, EnvState<T> &st, Sw
 
 // one internal substep of one environment, executed by the 16 lanes of its row
 template <typename T, typename Lds>
-XARM_HD void substep(const Grp &G, EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds) {
+XARM_HD void substep(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds) {
     Setup<T> S;
-    substep_setup<T, Lds>(st, qt, dt, lds, S);
+    substep_setup<T, Lds>(G, C, st, qt, dt, lds, S);
     XARM_LDS_FENCE();
     T tau[15];
     Sweep<T> W;
@@ -830,14 +1057,15 @@ XARM_HD void substep(const Grp &G, EnvState<T> &st, const T (&qt)[9], const T dt
     st.bw[0] = wb.x; st.bw[1] = wb.y; st.bw[2] = wb.z;
 }
 
-template <typename T, typename Lds> XARM_HD void sim_tick(const Grp &G, EnvState<T> &st, const T (&qt)[9], Lds lds) {
+template <typename T, typename Lds> XARM_HD void sim_tick(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, const T (&qt)[9], Lds lds) {
     const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
 #pragma unroll 1
-    for (int k = 0; k < xm::PNP_N_SUBSTEPS; k++) substep<T, Lds>(G, st, qt, dt, lds);
+    for (int k = 0; k < xm::PNP_N_SUBSTEPS; k++) substep<T, Lds>(G, C, st, qt, dt, lds);
 }
 
 // XarmPickAndPlace.reset (:121-127) = _reset_sim (:250-267) + _sample_goal (:269-287); same sequence as xk::env_reset
 template <typename T, typename Lds> XARM_HD void env_reset(const Grp &G, const EnvCfg &cfg, int64_t env, EnvState<T> &st, Lds lds) {
+    const ArmLane<T> C = arm_lane_consts<T>(G);
     T qt[9];
     const int64_t episode = (int64_t)st.episode + 1;
     const V3<T> start = mk<T>((T)xm::PNP_START_GRIPPER_POS[0], (T)xm::PNP_START_GRIPPER_POS[1], (T)xm::PNP_START_GRIPPER_POS[2]);
@@ -852,7 +1080,7 @@ template <typename T, typename Lds> XARM_HD void env_reset(const Grp &G, const E
             xk::sample_object(cfg, u, st);
             xk::sample_goal(cfg, u, st);
         }
-        sim_tick<T, Lds>(G, st, qt, lds);
+        sim_tick<T, Lds>(G, C, st, qt, lds);
     }
     st.steps = (T)0;
     st.episode = (T)episode;
@@ -862,6 +1090,7 @@ template <typename T, typename Lds> XARM_HD void env_reset(const Grp &G, const E
 template <typename T, typename Lds>
 XARM_HD void env_step(const Grp &G, const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (&obs)[xk::OBS_DIM], T &reward, bool &done,
                       bool &success, Lds lds) {
+    const ArmLane<T> C = arm_lane_consts<T>(G);
     st.steps += (T)1;
     T a[4], qt[9];
 #pragma unroll
@@ -877,7 +1106,7 @@ XARM_HD void env_step(const Grp &G, const EnvCfg &cfg, EnvState<T> &st, const T 
     xk::ik_solve(st.q, target, qt);
     qt[7] = qt[8] = g;
     st.mug = st.touch;
-    sim_tick<T, Lds>(G, st, qt, lds);
+    sim_tick<T, Lds>(G, C, st, qt, lds);
     xk::get_obs(st, obs);
     const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
     const T dist = xsqrt(dx * dx + dy * dy + dz * dz);

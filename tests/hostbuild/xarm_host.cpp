@@ -126,7 +126,8 @@ template <typename T> void coop_substep(int64_t E, double *state, const double *
         load(state + e * xk::STATE_DIM, s);
         T t[9]; for (int k = 0; k < 9; k++) t[k] = (T)qt[e * 9 + k];
         const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
-        for (int k = 0; k < n; k++) xc::substep<T>(xc::Grp(), s, t, dt, L);
+        const xc::ArmLane<T> C = xc::arm_lane_consts<T>(xc::Grp());
+        for (int k = 0; k < n; k++) xc::substep<T>(xc::Grp(), C, s, t, dt, L);
         store(s, state + e * xk::STATE_DIM);
     }
 }

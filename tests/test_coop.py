@@ -37,7 +37,7 @@ def test_coop_step_f32_within_conditioned_tolerance(hostcore, golden_rollout, pa
     for t in range(A.shape[0]):
         st, *_ = hostcore.coop_step(S[t], A[t], f32=1, seed=seed)
         parity.compare(st[:, parity.CONT], S[t + 1][:, parity.CONT], g[key + "_sens"][t], what="coop %s t=%d" % (key, t),
-                       frac_tight=0.9, max_exempt=0.1)
+                       frac_tight=0.9 if key == "rand" else 0.75, max_exempt=0.15 if key == "rand" else 0.25)
 
 
 def test_coop_reset_f64_equals_oracle(oracle, hostcore, golden_rollout):

@@ -12,10 +12,12 @@ ids rank*E .. (rank+1)*E-1; `--scaling strong`: the same number of environments 
 (gym_xarm_amd.distributed.shard_range).  No data-path collective either way.  Inputs are
 synthetic: a ring of 64 pre-generated uniform[-1,1] action tensors resident in HBM, so the timed region contains no
 RNG and no host->device traffic.  The timed window of K steps is repeated `--repeats` times back to back (default 3);
-`value` is the MEDIAN window (max over ranks per window), the others are listed.  `--episode-phase desync` (default)
-spreads the per-env step counters uniformly over the episode length before the warm-up, so that time-limit resets
-arrive at their steady-state rate (E / max_episode_steps per step) instead of all E at once every 50th step;
-`lockstep` keeps the counters as reset() leaves them.  Rank 0 prints ONE JSON line.
+`value` is the MEDIAN window (max over ranks per window), the others are listed.  `--episode-phase desync` spreads
+the per-env step counters uniformly over the episode length before the warm-up, so that time-limit resets arrive at
+their steady-state rate (E / max_episode_steps per step) instead of all E at once every 50th step; `lockstep` keeps the
+counters as reset() leaves them; the default `auto` picks the workload's own steady state - desync where an episode can
+end early by success (pnp, handover), lockstep where every episode has the same fixed length (reach, stack).
+Rank 0 prints ONE JSON line.
 
 `--workload` selects one of the other BASELINE.json configs for the same measurement (same JSON schema, its own
 metric name): reach = config 2 (XarmReach-v0, 4 096 envs), stack = config 4 (XarmPDStackTower-v0, 8 192 envs per
@@ -132,7 +134,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pnp")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--episode-phase", choices=["desync", "lockstep"], default="desync")
+    ap.add_argument("--episode-phase", choices=["auto", "desync", "lockstep"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the extra measurement of the opt-in lazy auto-reset mode")
     args = ap.parse_args()
@@ -186,6 +188,11 @@ def main():
     ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
     T_ep = env.max_episode_steps
+    if args.episode_phase == "auto":
+        # steady state of the workload: envs whose episodes can end early (success: PickAndPlace, Handover) drift apart
+        # and reset at a uniform rate; fixed-length episodes (Reach: 25 steps, StackTower: 50, never `done` before)
+        # start together and stay together for ever - one bulk reset every T_ep-th step IS their steady state
+        args.episode_phase = "desync" if args.workload in ("pnp", "handover") else "lockstep"
     if args.episode_phase == "desync":
         # steady state: episode phases uniform over the episode length, keyed by the global env id
         env.set_episode_steps((torch.arange(E, device=dev) + offset) * 7919 % T_ep)

@@ -1,19 +1,18 @@
-// xarm_hip.hip - gfx950 kernels and the C ABI (include/xarm_hip.h) of the batched
-// XarmPickAndPlace environment.
+// xarm_hip.hip - gfx950 kernels and the C ABI (include/xarm_hip.h) of the batched Xarm environments.
 //
-// Launch geometry: one thread per environment, one 64-lane wavefront per workgroup.  The fused
-// step keeps an environment's whole working set on chip for all 15 substeps x 50 solver sweeps:
-// ~400 VGPRs of per-env state/solver blocks (hence 1 wave per SIMD, __launch_bounds__(64)) plus
-// 96 floats per env of LDS (hand Jacobian S and T = M^-1 S^T), i.e. 24 KiB per workgroup.
-// 65 536 envs = 1024 workgroups = exactly 4 per CU on the 256 CUs; since workgroups are dealt
-// round-robin over the 8 XCDs and never communicate, no XCD-aware remap is needed.
-// HBM is touched once per env step: 54 state floats in, 54 out (structure-of-arrays, lane =
-// env, so every load/store is a fully coalesced 256-B wave access), 4 action floats in and the
-// 24+3+3+1 output floats + 2 flag bytes out (row-major at the API edge, 16-B vector stores).
-//
-// Episodes that end are compacted into a list (one wave-aggregated atomic per wavefront) and
-// re-initialised by k_reset, which runs the reference's 6 reset ticks only for those envs,
-// densely packed into wavefronts, instead of idling 63 lanes while one lane resets.
+// PickAndPlace launches (cores: xarm_core.h, xarm_coop_core.h):
+//   k_step        one thread per environment, one 64-lane wavefront per workgroup.  The fused step keeps an env's whole
+//                 working set on chip for all 15 substeps x 50 solver sweeps: ~450 VGPRs of per-env state / solver blocks
+//                 (hence 1 wave per SIMD, __launch_bounds__(64)) plus 149 floats per env of LDS (hand Jacobian S, T =
+//                 M^-1 S^T, A_hh, table slots: lane-private columns, 38 KB per workgroup).  65 536 envs = 1024 workgroups =
+//                 4 per CU; workgroups never communicate, so no XCD-aware remap is needed.
+//   k_step_coop / k_reset_coop   one environment per DPP row of 16 lanes (4 per wavefront), impulse-space sweep spread
+//                 over the row: the latency-optimal form for small batches and for the resets that follow a step.
+//   k_reset       the one-env-per-lane reset, for bulk resets (> coop_limit finished envs in one call).
+// HBM is touched once per env step: 54 state floats in, 54 out (structure-of-arrays, lane = env, every load/store a fully
+// coalesced 256-B wave access), 4 action floats in and the 24+3+3+1 output floats + 2 flag bytes out (row-major at the
+// API edge, 16-B vector stores).  Episodes that end are compacted into a list (one atomic per finished env) and
+// re-initialised by the reset kernel inside the same xarm_step call.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

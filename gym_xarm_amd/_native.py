@@ -25,7 +25,7 @@ class XarmConfig(C.Structure):
                 ("env_kind", C.c_int32), ("num_obj", C.c_int32), ("reward_type", C.c_int32),
                 ("goal_shape", C.c_int32), ("init_grasp_rate", C.c_float), ("goal_ground_rate", C.c_float),
                 ("auto_reset", C.c_int32), ("device", C.c_int32), ("same_side_rate", C.c_float), ("reset_coop_limit", C.c_int32),
-                ("step_coop_limit", C.c_int32), ("reserved", C.c_int32)]
+                ("step_coop_limit", C.c_int32), ("use_stand", C.c_int32)]
 
 
 class XarmDims(C.Structure):

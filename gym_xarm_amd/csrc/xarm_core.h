@@ -344,6 +344,7 @@ template <typename T> struct TablePoint {
 // Scene traits: what differs between the single-arm PickAndPlace scene and the dual-arm Handover scene.
 struct PnpScene {
     static constexpr int NARMS = 1;
+    static constexpr bool HAS_STAND = false;   // no static support box besides the table
     static constexpr double OBJ_HX = xm::PNP_OBJ_HALF[0], OBJ_HY = xm::PNP_OBJ_HALF[1], OBJ_HZ = xm::PNP_OBJ_HALF[2];
     static constexpr double OBJ_MASS = xm::PNP_OBJ_MASS;
     static constexpr double TIME_STEP = xm::PNP_TIME_STEP;              // p.setTimeStep: motor / gear max impulse = force * timeStep
@@ -669,6 +670,28 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 tp[s].id = put ? i : tp[s].id;
             }
             cnt += act ? 1 : 0;
+        }
+        if constexpr (Scene::HAS_STAND) {
+            // the static stand under the goal: up to four more support points (ids 8..11, no warm start) after the corners
+            V3<T> sp[4];
+            T sd[4];
+            Scene::template stand_points<T>(st.goal, cb, b0, b1, b2, sp, sd);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const T dist = sd[v];
+                const bool act = dist < (T)xm::SOLVER_MARGIN && dist > (T)Scene::STAND_MIN_GAP && cnt < NTS;
+                const V3<T> r = sp[v] - cb;
+                const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist * idt : -dist * idt;
+#pragma unroll
+                for (int s = 0; s < NTS; s++) {
+                    const bool put = act && cnt == s;
+                    tp[s].r.x = put ? r.x : tp[s].r.x; tp[s].r.y = put ? r.y : tp[s].r.y; tp[s].r.z = put ? r.z : tp[s].r.z;
+                    tp[s].vt = put ? vt : tp[s].vt;
+                    tp[s].lam[0] = put ? (T)0 : tp[s].lam[0];
+                    tp[s].id = put ? 8 + v : tp[s].id;
+                }
+                cnt += act ? 1 : 0;
+            }
         }
     }
     const T mu_t = (T)(xm::MU_OBJECT * xm::MU_TABLE);

@@ -35,11 +35,13 @@ struct EnvCfg {
     int64_t env_id_offset;
     float same_side_rate;
     int goal_shape; // 1 = 'ground'
+    int use_stand;  // config['use_stand'] (:391-392): kernels instantiated with HandoverStandScene
     int reward_type; // 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199)
 };
 
 struct HandoverScene {
     static constexpr int NARMS = 2;
+    static constexpr bool HAS_STAND = false;
     static constexpr double OBJ_HX = xm::HO_OBJ_HALF[0], OBJ_HY = xm::HO_OBJ_HALF[1], OBJ_HZ = xm::HO_OBJ_HALF[2];
     static constexpr double OBJ_MASS = xm::HO_OBJ_MASS;
     static constexpr double TIME_STEP = xm::HO_TIME_STEP;
@@ -65,14 +67,61 @@ struct HandoverScene {
     }
 };
 
+// config['use_stand'] (:391-392): urdf/my_stand.urdf, a fixed 0.07 x 0.06 x 0.01 box whose top sits 25 mm under the goal.
+// Contact model (model JSON handover._stand_cite, restated by the oracle): the stick's most downward face against the
+// stand's top rectangle - the overlap of the face's axis-aligned footprint with the rectangle (the env zeroes the
+// stick's roll and yaw every step, :282-297) gives up to four support points on the face's plane, normal +z.
+struct HandoverStandScene : HandoverScene {
+    static constexpr bool HAS_STAND = true;
+    static constexpr double STAND_MIN_GAP = -(2.0 * xm::HO_STAND_HALF[2] + 0.01);
+    // sp[v]: support point v on the face's plane, sd[v]: its gap to the stand's top (1e30 when there is no overlap)
+    template <typename T> static XARM_HD void stand_points(const T (&goal)[3], V3<T> cb, V3<T> b0, V3<T> b1, V3<T> b2, V3<T> (&sp)[4], T (&sd)[4]) {
+        const T top = goal[2] - (T)xm::HO_STAND_BELOW_GOAL + (T)xm::HO_STAND_HALF[2];
+        // the face (axis kf, sign sg) whose outward normal points most downward; ties -> the first in (k, -/+) order
+        const T z0 = b0.z, z1 = b1.z, z2 = b2.z;
+        int kf = 0;
+        T sg = (T)-1, best = -z0;
+        if (z0 < best) { best = z0; kf = 0; sg = (T)1; }
+        if (-z1 < best) { best = -z1; kf = 1; sg = (T)-1; }
+        if (z1 < best) { best = z1; kf = 1; sg = (T)1; }
+        if (-z2 < best) { best = -z2; kf = 2; sg = (T)-1; }
+        if (z2 < best) { best = z2; kf = 2; sg = (T)1; }
+        const T hx = (T)OBJ_HX, hy = (T)OBJ_HY, hz = (T)OBJ_HZ;
+        const V3<T> af = xk::selv(kf == 0, b0, xk::selv(kf == 1, b1, b2));          // face axis
+        const V3<T> a1 = xk::selv(kf == 0, b1, xk::selv(kf == 1, b2, b0));          // the two in-face axes (k+1, k+2)
+        const V3<T> a2 = xk::selv(kf == 0, b2, xk::selv(kf == 1, b0, b1));
+        const T hf = kf == 0 ? hx : (kf == 1 ? hy : hz), h1 = kf == 0 ? hy : (kf == 1 ? hz : hx), h2 = kf == 0 ? hz : (kf == 1 ? hx : hy);
+        const V3<T> nf = af * sg, fc = cb + nf * hf;
+        T xlo = (T)1e30, xhi = (T)-1e30, ylo = (T)1e30, yhi = (T)-1e30;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const T s1 = (v & 1) ? h1 : -h1, s2 = (v & 2) ? h2 : -h2;
+            const T x = fc.x + s1 * a1.x + s2 * a2.x, y = fc.y + s1 * a1.y + s2 * a2.y;
+            xlo = x < xlo ? x : xlo; xhi = x > xhi ? x : xhi; ylo = y < ylo ? y : ylo; yhi = y > yhi ? y : yhi;
+        }
+        const T sx0 = goal[0] - (T)xm::HO_STAND_HALF[0], sx1 = goal[0] + (T)xm::HO_STAND_HALF[0];
+        const T sy0 = goal[1] - (T)xm::HO_STAND_HALF[1], sy1 = goal[1] + (T)xm::HO_STAND_HALF[1];
+        const T ox0 = xlo > sx0 ? xlo : sx0, ox1 = xhi < sx1 ? xhi : sx1, oy0 = ylo > sy0 ? ylo : sy0, oy1 = yhi < sy1 ? yhi : sy1;
+        const bool overlap = ox0 < ox1 && oy0 < oy1;
+        const T inz = (T)1 / nf.z;                                                  // nf.z <= -1/sqrt(3)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const T x = (v & 1) ? ox1 : ox0, y = (v & 2) ? oy1 : oy0;
+            const T z = fc.z - (nf.x * (x - fc.x) + nf.y * (y - fc.y)) * inz;
+            sp[v] = mk<T>(x, y, z);
+            sd[v] = overlap ? z - top : (T)1e30;
+        }
+    }
+};
+
 // one lane = one arm: st.q/qd/lam_p[0..3]/touch/mug are the arm's, the rest is the lane's copy of the shared state
 template <typename T> struct Lane {
     EnvState<T> st;
     T ft; // finger motor target of this arm (persists across reset ticks, :265-268 vs :347-353)
 };
 
-template <typename T, typename Lds, typename Xchg> XARM_HD void tick(Lane<T> &L, const T (&qt)[9], Lds lds, int arm, Xchg x) {
-    xk::substep<T, Lds, HandoverScene, Xchg>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x);
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene> XARM_HD void tick(Lane<T> &L, const T (&qt)[9], Lds lds, int arm, Xchg x) {
+    xk::substep<T, Lds, Scene, Xchg>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x);
 }
 
 template <typename T> XARM_HD V3<T> eef_pos(const Lane<T> &L, int arm) {
@@ -148,7 +197,7 @@ template <typename T> XARM_HD void lane_init(const EnvCfg &cfg, int64_t env, Lan
     sample_goal(cfg, u, L);
 }
 
-template <typename T, typename Lds, typename Xchg>
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds lds, Xchg x) {
     const int64_t episode = (int64_t)L.st.episode + 1;
     T qt[9], u[8];
@@ -161,7 +210,7 @@ XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds
             draws(cfg, env, episode, u);
             sample_object(u, L);
         }
-        tick<T, Lds, Xchg>(L, qt, lds, arm, x);
+        tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
     }
     sample_goal(cfg, u, L);
     L.st.steps = (T)0;
@@ -189,7 +238,7 @@ XARM_HD T dense_reward(const Lane<T> &L, int arm, T d_og, Xchg x) {
     return ((T)2 + (T)0.25 * ((T)1 - xk::xtanh(d_og))) * k;
 }
 
-template <typename T, typename Lds, typename Xchg>
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
     L.st.steps += (T)1;
     T a[4], qt[9];
@@ -220,7 +269,7 @@ XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &
         for (int k = 0; k < 3; k++) { L.st.bv[k] = (T)0; L.st.bw[k] = (T)0; }
     }
 #pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg>(L, qt, lds, arm, x);
+    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
     const T dx = L.st.bp[0] - L.st.goal[0], dy = L.st.bp[1] - L.st.goal[1], dz = L.st.bp[2] - L.st.goal[2];
     const T dist = xk::xsqrt(dx * dx + dy * dy + dz * dz);
     success = dist < (T)xm::HO_DISTANCE_THRESHOLD;

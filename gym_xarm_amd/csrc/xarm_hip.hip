@@ -465,6 +465,7 @@ __global__ __launch_bounds__(WG) void k_ho_init(KParams P) {
     xh::lane_init<float>(P.hcfg, e, L);
     ho_store(P, e, arm, L);
 }
+template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    xh::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
+    xh::lane_step<float, DevLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
     const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
         }
     }
 }
+template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                  float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restric
     DevLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
     ho_load(P, e_in, arm, L);
-    xh::lane_reset<float, DevLds, DppXchg>(P.hcfg, e_in, L, arm, lds, DppXchg());
+    xh::lane_reset<float, DevLds, DppXchg, Scene>(P.hcfg, e_in, L, arm, lds, DppXchg());
     const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     if (obs_out) ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -702,6 +704,12 @@ static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
         if (_e != hipSuccess) return fail(h, XARM_E_HIP, #call ": %s", hipGetErrorString(_e)); \
     } while (0)
 
+static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
+                            hipStream_t st) {
+    if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    else k_ho_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+}
+
 // PickAndPlace reset of the envs in list[0 .. *count) (null: all): the cooperative kernel takes counts up to
 // kp.coop_limit, the one-env-per-lane kernel the rest; both are launched, the one out of its range exits at once.
 static void launch_pnp_reset(xarm_handle *h, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
@@ -753,6 +761,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (!reach && !stack && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
     if (handover && cfg->reward_type != 0 && cfg->reward_type != XARM_REWARD_DENSE)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover reward_type is sparse (hard-wired in the reference, xarm_handover.py:40) or dense (:184-199)");
+    if (cfg->use_stand && !handover) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: use_stand belongs to XarmHandover (xarm_handover.py:391-392)");
     if (cfg->auto_reset < 0 || cfg->auto_reset > XARM_AUTO_RESET_LAZY) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: auto_reset must be 0, 1 or XARM_AUTO_RESET_LAZY");
     if (cfg->auto_reset == XARM_AUTO_RESET_LAZY && cfg->env_kind != XARM_ENV_PICK_AND_PLACE)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: lazy auto-reset is implemented for XarmPickAndPlace only");
@@ -798,6 +807,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
     h->kp.hcfg.same_side_rate = cfg->same_side_rate;
     h->kp.hcfg.goal_shape = cfg->goal_shape;
+    h->kp.hcfg.use_stand = handover && cfg->use_stand ? 1 : 0;
     h->kp.hcfg.reward_type = cfg->reward_type == XARM_REWARD_DENSE ? 1 : 0;
     h->kp.rcfg.seed = cfg->seed;
     h->kp.rcfg.env_id_offset = cfg->env_id_offset;
@@ -865,12 +875,12 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
         HIPCHK(h, hipMemsetAsync(h->mask_count, 0, sizeof(int), st));
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
-        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
     } else {
         if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
-        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
     }
@@ -902,9 +912,12 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (stack)
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                        terminal_obs_dev, h->done_list, cnt, stale);
+    else if (handover && h->kp.hcfg.use_stand)
+        k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
+                                                                           success_dev, terminal_obs_dev, h->done_list, cnt, stale);
     else if (handover)
-        k_ho_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                       terminal_obs_dev, h->done_list, cnt, stale);
+        k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
+                                                                      success_dev, terminal_obs_dev, h->done_list, cnt, stale);
     else if (reach)
         k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                       terminal_obs_dev, h->done_list, cnt, stale);
@@ -917,7 +930,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
     if (h->kp.auto_reset) {
         if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
-        else if (handover) k_ho_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else if (handover) launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
     }

@@ -322,7 +322,8 @@ HANDOVER_CONFIG_DEFAULTS = {"GUI": False, "num_obj": 1, "same_side_rate": 0.5, "
 class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
     """E independent XarmHandover-v0 environments (/root/reference/gym_xarm/envs/xarm_handover.py:19): two xArm7 +
     Panda-gripper arms, one stick, two tables with a gap; obs 29 (:325-329), action 8 (:118), sparse reward
-    -[d > 0.05] (:177-183), done = success or 100 steps (:138 + registry).  num_obj = 1, use_stand = False."""
+    -[d > 0.05] (:177-183) or the staged dense reward (:184-199), done = success or 100 steps (:138 + registry),
+    config['use_stand'] (:391-392): a static stand under the goal.  num_obj = 1."""
 
     ENV_KIND = _native.ENV_HANDOVER
     AG_SLICE = slice(0, 3)    # achieved_goal = object position (xarm_handover.py:325-336)
@@ -332,8 +333,6 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
         cfg.update(config or {})
         if cfg["num_obj"] != 1:
             raise NotImplementedError("this build supports num_obj == 1")
-        if cfg["use_stand"]:
-            raise NotImplementedError("use_stand=True (a static stand under the goal) is not built")
         # the reference hard-wires reward_type = 'sparse' (xarm_handover.py:40); its staged 'dense' branch (:184-199) is
         # offered as an opt-in config key (the undefined `d` of its last stage = object-to-goal distance)
         cfg.setdefault("reward_type", "sparse")
@@ -346,7 +345,7 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
                                   _native.REWARD_TYPES[self.config["reward_type"]],
                                   1 if self.config["goal_shape"] == "ground" else 0, 0.0, 0.0, int(self._auto_reset),
                                   self.device.index if self.device.index is not None else torch.cuda.current_device(),
-                                  float(self.config["same_side_rate"]), 0)
+                                  float(self.config["same_side_rate"]), 0, 0, int(bool(self.config["use_stand"])))
 
     def debug_substeps(self, q_target, n):
         raise NotImplementedError

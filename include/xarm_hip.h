@@ -86,7 +86,8 @@ typedef struct xarm_config {
     int32_t step_coop_limit;  /* PickAndPlace: a handle of at most this many envs also STEPS on the cooperative kernel
                                  (the one-env-per-lane launch would leave most SIMDs without a wavefront);
                                  0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never */
-    int32_t reserved;
+    int32_t use_stand;        /* XarmHandover config['use_stand'] (xarm_handover.py:391-392): a static 0.07 x 0.06 x 0.01 box
+                                 whose top sits 25 mm under the goal; 0 = parked away (the BASELINE configuration) */
 } xarm_config;                /* 72 bytes */
 #define XARM_RESET_COOP_LIMIT_DEFAULT 8192
 /* PickAndPlace handles of at most this many envs step on the cooperative kernel as well (env XARM_STEP_COOP_LIMIT) */

@@ -73,7 +73,8 @@ class XoHoCfg(C.Structure):
                 ("eff_init_pos", (_d * 3) * 2), ("joint_init_pos", _d * 9), ("base_pos", (_d * 3) * 2), ("base_yaw", _d * 2),
                 ("finger_motor_force", _d), ("distance_threshold", _d), ("obj_half", _d * 3), ("eef2grip", _d * 3),
                 ("table_x_min", _d), ("table_x_max", _d), ("table_half_y", _d), ("ground_z", _d),
-                ("reset_ticks", _i), ("max_episode_steps", _i), ("reward_type", _i), ("reserved", _i)]
+                ("reset_ticks", _i), ("max_episode_steps", _i), ("reward_type", _i), ("use_stand", _i),
+                ("stand_half", _d * 3), ("stand_below_goal", _d)]
 
 
 HO_STATE_DIM, HO_OBS_DIM, HO_ACT_DIM = 76, 29, 8
@@ -315,13 +316,17 @@ class OracleReach:
 class OracleHandover:
     """Batched CPU XarmHandover-v0 (xarm_handover.py, num_obj = 1, use_stand False), float64."""
 
-    def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground", reward_type="sparse"):
+    def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground", reward_type="sparse", use_stand=False):
         self.L = lib()
         js = load_model_json()
         self.m = build_model(js)
         h = js["handover"]
         c = XoHoCfg()
         c.reward_type = {"sparse": 0, "dense": 1}[reward_type]
+        c.use_stand = int(bool(use_stand))
+        c.stand_below_goal = h["stand_below_goal"]
+        for i in range(3):
+            c.stand_half[i] = h["stand_half"][i]
         c.seed, c.env_id_offset, c.same_side_rate = seed, env_id_offset, same_side_rate
         c.goal_shape = 1 if goal_shape == "ground" else 0
         for k in ("n_ticks", "time_step", "action_dt", "max_vel", "max_gripper_vel", "gripper_low", "gripper_high", "height_offset",

@@ -140,7 +140,9 @@ typedef struct {
     double finger_motor_force, distance_threshold, obj_half[3], eef2grip[3];
     double table_x_min, table_x_max, table_half_y, ground_z; /* tables cover table_x_min <= |x| <= table_x_max */
     int32_t reset_ticks, max_episode_steps;
-    int32_t reward_type, reserved; /* 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199) */
+    int32_t reward_type;        /* 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199) */
+    int32_t use_stand;          /* config['use_stand'] (:391-392): a static box under the goal */
+    double stand_half[3], stand_below_goal; /* my_stand.urdf box 0.07 x 0.06 x 0.01; centre = goal - (0,0,stand_below_goal) */
 } xo_ho_cfg;
 int xo_ho_init(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state);
 int xo_ho_reset(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,

@@ -227,8 +227,10 @@ template <typename T> void *ho_thread(void *p) {
         T r = 0; bool d = false, su = false;
         if (J.mode == 0) {
             T a[4]; for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
-            xh::lane_step<T>(L, J.arm, a, r, d, su, hl, x, J.cfg.reward_type);
-        } else xh::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
+            if (J.cfg.use_stand) xh::lane_step<T, HostLds<T>, PairXchg, xh::HandoverStandScene>(L, J.arm, a, r, d, su, hl, x, J.cfg.reward_type);
+            else xh::lane_step<T>(L, J.arm, a, r, d, su, hl, x, J.cfg.reward_type);
+        } else if (J.cfg.use_stand) xh::lane_reset<T, HostLds<T>, PairXchg, xh::HandoverStandScene>(J.cfg, e, L, J.arm, hl, x);
+        else xh::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
         T o8[8];
         xh::arm_obs(L, J.arm, o8);
         pthread_barrier_wait(&J.sh->bar);   // both lanes finished computing before anyone overwrites the row
@@ -257,9 +259,10 @@ template <typename T> void ho_run(int mode, const xh::EnvCfg &cfg, int64_t E, do
 }
 
 extern "C" {
-static int g_ho_reward_type = 0;
+static int g_ho_reward_type = 0, g_ho_use_stand = 0;
 void xh_ho_set_reward_type(int rt) { g_ho_reward_type = rt; }   // 0 sparse, 1 the staged dense reward
-static xh::EnvCfg hcfg(uint64_t seed, int64_t off, double ssr, int gs) { xh::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.same_side_rate = (float)ssr; c.goal_shape = gs; c.reward_type = g_ho_reward_type; return c; }
+void xh_ho_set_use_stand(int us) { g_ho_use_stand = us; }
+static xh::EnvCfg hcfg(uint64_t seed, int64_t off, double ssr, int gs) { xh::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.same_side_rate = (float)ssr; c.goal_shape = gs; c.reward_type = g_ho_reward_type; c.use_stand = g_ho_use_stand; return c; }
 void xh_ho_init(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state) {
     auto c = hcfg(seed, off, ssr, gs);
     for (int64_t e = 0; e < E; e++) for (int a = 1; a >= 0; a--) {

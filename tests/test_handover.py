@@ -143,6 +143,57 @@ def test_dense_reward_hostcore_f64_equals_oracle(oracle, hostcore, groll):
     assert stages == {0, 1, 2, 3}
 
 
+def _stand_scene(oracle, E=6, seed=3):
+    """sticks placed 2 mm above their (air) goals: on the stand's centre (4 envs, one goal on the table), 3 cm off
+    centre (still supported) and 9 cm off centre (centre of mass beyond the stand: tips over)"""
+    env = oracle.OracleHandover(E, seed=seed, goal_shape="air", use_stand=True)
+    env.reset()
+    st = env.get_state()
+    goals = np.array([[0.2, 0.0, 0.15], [0.15, 0.1, 0.1], [-0.2, -0.05, 0.18], [0.25, 0.0, 0.025], [0.2, 0.0, 0.15], [0.2, 0.0, 0.15]])
+    st[:, 51:54] = goals
+    st[:, 38:41] = goals + [0, 0, 0.002]
+    st[4, 38] += 0.03
+    st[5, 38] += 0.09
+    st[:, 41:45] = [0, 0, 0, 1]
+    st[:, 45:51] = 0
+    return env, st
+
+
+def test_use_stand_statics_in_the_oracle(oracle):
+    """config['use_stand'] (xarm_handover.py:391-392): the static stand sits 25 mm under the goal, so a stick laid on it
+    rests AT the goal and the episode succeeds; without the stand the same stick falls to the table"""
+    env, st = _stand_scene(oracle)
+    env.set_state(st)
+    for k in range(12):
+        obs, ag, dg, rew, done, succ = env.step(np.zeros((6, 8)))
+    s = env.get_state()
+    assert np.allclose(s[:5, 40], s[:5, 53], atol=1e-3) and succ[:5].all() and (rew[:5] == 0).all()      # resting at goal height
+    assert s[5, 40] < s[5, 53] - 0.03 and not succ[5]                                                    # unsupported: tipping off
+    off = oracle.OracleHandover(6, seed=3, goal_shape="air", use_stand=False)
+    off.reset()
+    off.set_state(st)
+    for k in range(12):
+        _, _, _, _, _, succ0 = off.step(np.zeros((6, 8)))
+    s0 = off.get_state()
+    assert np.allclose(s0[:, 40], 0.025, atol=2e-3) and succ0[3] and not succ0[[0, 1, 2, 4, 5]].any()  # fell to the table / rests on it
+
+
+def test_use_stand_hostcore_f64_equals_oracle(oracle, hostcore):
+    env, st = _stand_scene(oracle)
+    rng = np.random.default_rng(0)
+    for k in range(6):
+        a = rng.uniform(-0.3, 0.3, (6, 8))
+        env.set_state(st)
+        env.step(a)
+        nxt = env.get_state()
+        hs, *_ = hostcore.ho_step(st, a, f32=0, seed=3, gs=0, use_stand=1)
+        np.testing.assert_allclose(hs, nxt, atol=1e-9)
+        h32, *_ = hostcore.ho_step(st, a, f32=1, seed=3, gs=0, use_stand=1)
+        assert np.median(np.abs(h32 - nxt)[:, :51].max(axis=1)) < 2e-4
+        st = nxt
+    assert (nxt[:, 40] > 0.05).sum() >= 3            # several sticks are still up on their stands after six steps of arm motion
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_gpu_handover_replays_golden_rollout(groll, parity):
@@ -253,4 +304,48 @@ def test_gpu_handover_dense_reward(oracle, groll):
     assert float(rew.max()) <= 1.0 + 1e-6 and float(rew.min()) >= 0.0           # staged reward is scaled into [0, 1]
     with pytest.raises(Exception, match="relabel"):
         env.compute_reward(torch.zeros(2, 3), torch.zeros(2, 3))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_handover_use_stand(oracle):
+    """use_stand=True through the C ABI: statics on the stand and transition parity against the oracle"""
+    import torch
+    import gym_xarm_amd as gx
+    from oracle import parity
+    ora, st = _stand_scene(oracle)
+    E = st.shape[0]
+    cfg = dict(gx.vec_env.HANDOVER_CONFIG_DEFAULTS, use_stand=True, goal_shape="air")
+    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=3, auto_reset=False, config=cfg)
+    env.set_state(st)
+    for k in range(12):
+        obs, rew, done, info = env.step(torch.zeros(E, 8))
+    s = env.get_state().cpu().numpy()
+    assert np.allclose(s[:5, 40], s[:5, 53], atol=2e-3) and info["is_success"].cpu().numpy()[:5].all() and s[5, 40] < s[5, 53] - 0.03
+    # replay oracle transitions under random arm motion from the oracle's states
+    rng = np.random.default_rng(1)
+    n_tight, n = 0, 0
+    for k in range(8):
+        a = rng.uniform(-0.4, 0.4, (E, 8))
+        ora.set_state(st)
+        ora.step(a)
+        nxt = ora.get_state()
+        sens = np.zeros(E)
+        for j in range(2):
+            sp = st.copy()
+            sp[:, CONT] += np.random.default_rng(100 * k + j).uniform(-1e-6, 1e-6, size=(E, CONT.size))
+            qn = sp[:, 41:45]
+            sp[:, 41:45] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+            ora.set_state(sp)
+            ora.step(a)
+            sens = np.maximum(sens, np.abs(ora.get_state()[:, CONT] - nxt[:, CONT]).max(axis=1))
+        env.set_state(st)
+        env.step(torch.tensor(a, dtype=torch.float32))
+        dev = env.get_state().cpu().numpy().astype(np.float64)
+        stats = parity.compare(dev[:, CONT], nxt[:, CONT], sens, what="handover stand t=%d" % k, frac_tight=0.5, max_exempt=0.5)
+        n_tight += stats["frac_tight"] * E
+        n += E
+        st = nxt
+    assert n_tight >= 0.8 * n
+    # without the flag the same scene lets the sticks fall (and the default config rejects nothing)
     env.close()

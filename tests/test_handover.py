@@ -77,8 +77,8 @@ def test_hostcore_lane_pair_f64_equals_oracle(hostcore, groll):
     np.testing.assert_allclose(st, g["states"][0][:6], atol=1e-9)
     np.testing.assert_allclose(obs, g["reset_obs"][:6], atol=1e-9)
     n_ok, n_all = 0, 0
-    sub = slice(0, 10)    # the two-thread lane emulation is slow: 10 envs, every third step (incl. the two-arm contact phase)
-    for t in range(0, g["actions"].shape[0], 3):
+    sub = slice(0, 6)     # the two-thread lane emulation is slow: 6 envs, every fourth step (incl. the two-arm contact phase)
+    for t in range(0, g["actions"].shape[0], 4):
         st, obs, ag, dg, rew, done, succ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=0, seed=2)
         ok = g["sens"][t][sub] < 1e-2
         err = np.abs(st - g["states"][t + 1][sub]).max(axis=1)
@@ -92,8 +92,8 @@ def test_hostcore_lane_pair_f64_equals_oracle(hostcore, groll):
 
 def test_hostcore_lane_pair_f32_within_tolerance(hostcore, groll, parity):
     g = groll
-    sub = slice(0, 10)
-    for t in range(1, g["actions"].shape[0], 6):
+    sub = slice(0, 8)
+    for t in range(1, g["actions"].shape[0], 9):
         st, *_ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=1, seed=2)
         parity.compare(st[:, CONT], g["states"][t + 1][sub][:, CONT], g["sens"][t][sub], what="handover f32 t=%d" % t, frac_tight=0.7, max_exempt=0.3)
 
@@ -129,10 +129,10 @@ def test_dense_reward_matches_reference_formula(oracle, gref):
 def test_dense_reward_hostcore_f64_equals_oracle(oracle, hostcore, groll):
     """along the scripted hand-over (all four stages occur): oracle.step(dense) vs the lane-pair core"""
     g = groll
-    sub = slice(0, 10)
-    ora = oracle.OracleHandover(10, seed=2, reward_type="dense")
+    sub = slice(0, 8)
+    ora = oracle.OracleHandover(8, seed=2, reward_type="dense")
     stages = set()
-    for t in range(0, g["actions"].shape[0], 2):
+    for t in range(0, g["actions"].shape[0], 3):
         ora.set_state(g["states"][t][sub])
         o = ora.step(g["actions"][t][sub])
         st, obs, ag, dg, rew, done, succ = hostcore.ho_step(g["states"][t][sub], g["actions"][t][sub], f32=0, seed=2, rt=1)
@@ -181,7 +181,7 @@ def test_use_stand_statics_in_the_oracle(oracle):
 def test_use_stand_hostcore_f64_equals_oracle(oracle, hostcore):
     env, st = _stand_scene(oracle)
     rng = np.random.default_rng(0)
-    for k in range(6):
+    for k in range(4):
         a = rng.uniform(-0.3, 0.3, (6, 8))
         env.set_state(st)
         env.step(a)
@@ -191,7 +191,7 @@ def test_use_stand_hostcore_f64_equals_oracle(oracle, hostcore):
         h32, *_ = hostcore.ho_step(st, a, f32=1, seed=3, gs=0, use_stand=1)
         assert np.median(np.abs(h32 - nxt)[:, :51].max(axis=1)) < 2e-4
         st = nxt
-    assert (nxt[:, 40] > 0.05).sum() >= 3            # several sticks are still up on their stands after six steps of arm motion
+    assert (nxt[:, 40] > 0.05).sum() >= 3            # several sticks are still up on their stands after four steps of arm motion
 
 
 # ------------------------------------------------------------------------------------------- GPU

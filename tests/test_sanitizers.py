@@ -26,9 +26,12 @@ void xh_ho_step(int, uint64_t, int64_t, double, int, int64_t, double*, const dou
 void xh_st_init(int, uint64_t, int64_t, int, int64_t, double*);
 void xh_st_reset(int, uint64_t, int64_t, int, int64_t, double*, const uint8_t*, double*, double*, double*);
 void xh_st_step(int, uint64_t, int64_t, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*);
+void xh_coop_step(int, uint64_t, int64_t, double, double, int, int, int64_t, double*, const double*, double*, double*, double*, double*, uint8_t*, uint8_t*);
+void xh_coop_reset(int, uint64_t, int64_t, double, double, int, int, int64_t, double*, const uint8_t*, double*, double*, double*);
+void xh_ho_set_use_stand(int);
 }
 int main() {
-    const int64_t E = 6;
+    const int64_t E = 3;
     double *st = (double*)calloc(E * 54, 8), *obs = (double*)calloc(E * 24, 8), *ag = (double*)calloc(E * 3, 8), *dg = (double*)calloc(E * 3, 8);
     double *rew = (double*)calloc(E, 8), *act = (double*)calloc(E * 4, 8);
     uint8_t *done = (uint8_t*)calloc(E, 1), *succ = (uint8_t*)calloc(E, 1);
@@ -36,14 +39,18 @@ int main() {
     for (int f32 = 0; f32 < 2; f32++) {
         xh_init(f32, 3, 0, 0.3, 0.3, 0, 2, E, st);
         xh_reset(f32, 3, 0, 0.3, 0.3, 0, 2, E, st, 0, obs, ag, dg);
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < 2; t++) {
             for (int k = 0; k < E * 4; k++) act[k] = ((t * 7 + k * 13) % 21) / 10.0 - 1.0;
             xh_step(f32, 3, 0, 0.3, 0.3, 0, 2, E, st, act, obs, ag, dg, rew, done, succ);
         }
+        // the cooperative (16 lanes per env) core: one step and one reset of one env (all four row-set instantiations
+        // are compiled; init_grasp_rate 0.3 puts objects between the fingers in some envs)
+        xh_coop_step(f32, 3, 0, 0.3, 0.3, 0, 2, 1, st, act, obs, ag, dg, rew, done, succ);
+        xh_coop_reset(f32, 3, 0, 0.3, 0.3, 0, 2, 1, st, 0, obs, ag, dg);
         double *rs = (double*)calloc(E * 45, 8), *ro = (double*)calloc(E * 8, 8);
         xh_reach_init(f32, 1, 0, 2, E, rs);
         xh_reach_reset(f32, 1, 0, 2, E, rs, 0, ro, ag, dg);
-        for (int t = 0; t < 3; t++) xh_reach_step(f32, 1, 0, 2, E, rs, act, ro, ag, dg, rew, done, succ, fut);
+        for (int t = 0; t < 2; t++) xh_reach_step(f32, 1, 0, 2, E, rs, act, ro, ag, dg, rew, done, succ, fut);
         free(rs); free(ro);
         // StackTower: two lanes (threads) per env; env 0 gets two overlapping cubes so that the cube/cube manifold
         // (clipped polygon in the lane's LDS columns) and its solver rows run under the sanitizers too
@@ -62,6 +69,10 @@ int main() {
         xh_ho_init(f32, 9, 0, 0.5, 1, 1, hs);
         xh_ho_reset(f32, 9, 0, 0.5, 1, 1, hs, 0, ho, ag, dg);
         xh_ho_step(f32, 9, 0, 0.5, 1, 1, hs, sa, ho, ag, dg, rew, done, succ);
+        xh_ho_set_use_stand(1);              // the stand's support points (HandoverStandScene)
+        hs[38] = hs[51]; hs[39] = hs[52]; hs[40] = hs[53] + 0.002;
+        xh_ho_step(f32, 9, 0, 0.5, 1, 1, hs, sa, ho, ag, dg, rew, done, succ);
+        xh_ho_set_use_stand(0);
         free(hs); free(ho);
         free(ss); free(so); free(sg); free(sd); free(sa);
     }
@@ -90,7 +101,8 @@ def test_kernel_core_under_asan_ubsan(tmp_path):
     main.write_text(MAIN)
     exe = tmp_path / "san_core"
     # -g1: line tables only (full debug info of the fully inlined templates triples the compile time)
-    subprocess.check_call(["g++", "-O1", "-g1", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    # -O0: the fully unrolled templates take 2 min to compile at -O1 under the sanitizers, 25 s at -O0
+    subprocess.check_call(["g++", "-O0", "-g1", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-Wno-unknown-pragmas", "-o", str(exe), str(main), os.path.join(ROOT, "tests", "hostbuild", "xarm_host.cpp")])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))

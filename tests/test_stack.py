@@ -136,7 +136,7 @@ def test_stack_host_f64_both_arms_on_one_cube(oracle, host):
     st = ora.get_state()
     act = np.zeros((2, 8))
     act[:, 3] = act[:, 7] = -1
-    for _ in range(3):
+    for _ in range(2):
         st, *_ = host.st_step(st, act, f32=0, seed=5)
         ora.step(act)
         assert np.abs(st - ora.get_state()).max() < 1e-9

@@ -48,6 +48,8 @@ WORKLOADS = {
 }
 
 
+COOP_STEP_KERNEL = {"pnp": "k_step_coop", "reach": "k_reach_step_coop"}   # batches <= xarm_config.step_coop_limit
+
 WORKLOAD_NAMES = {
     "pnp": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",
     "reach": "XarmReach-v0 (XarmReachEnv, sparse reward; BASELINE config 2)",
@@ -188,6 +190,11 @@ def main():
     ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
     T_ep = env.max_episode_steps
+    # which kernel family this handle runs (include/xarm_hip.h xarm_kernel_limits): the cooperative kernels serve batches
+    # / reset lists up to the limits, the one-env-per-lane kernels the rest
+    reset_limit, step_limit = env.kernel_limits() if hasattr(env, "kernel_limits") else (0, 0)
+    if E <= step_limit and args.workload in COOP_STEP_KERNEL:
+        kernel_name = COOP_STEP_KERNEL[args.workload]
     if args.episode_phase == "auto":
         # steady state of the workload: envs whose episodes can end early (success: PickAndPlace, Handover) drift apart
         # and reset at a uniform rate; fixed-length episodes (Reach: 25 steps, StackTower: 50, never `done` before)
@@ -273,7 +280,8 @@ def main():
             tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
             valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction, step kernel only)",
                     "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu}
-        reset_kernel = {"pnp": "k_reset_coop (<= 8192 finished envs per call) / k_reset", "reach": "k_reach_reset",
+        reset_kernel = {"pnp": "k_reset_coop (<= %d finished envs per call) / k_reset" % reset_limit,
+                        "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
                         "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
         out = {
             "metric": "env steps/sec (whole node), %s" % env_id, "value": value, "unit": "env steps/s", "n_gpus": world,

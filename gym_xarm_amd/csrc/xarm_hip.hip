@@ -24,6 +24,7 @@
 #include "xarm_handover_core.h"
 #include "xarm_stack_core.h"
 #include "xarm_coop_core.h"
+#include "xarm_reach_coop_core.h"
 
 namespace {
 
@@ -195,13 +196,23 @@ __global__ __launch_bounds__(WG) void k_reset(KParams P, const int *__restrict__
 // the rest of the GPU idles.  Rows beyond the list shadow its last entry (the wavefront stays convergent) and store
 // nothing; lane 0 of a row writes the environment back.
 constexpr int COOP_ENVS = WG / xc::GL;
+// A cooperative workgroup owns 4 consecutive envs = 16 B of every state column, an HBM line holds 16-32 envs.  Under the
+// default round-robin of workgroups over the 8 XCDs (one private L2 each) every XCD fetched - and partially wrote -
+// every line: 5x the algorithmic bytes measured at 4 096 envs (profiles/r02e_reach_pmc_summary.json).  This bijective
+// remap (valid for any grid size) gives the workgroups that share an XCD one contiguous env range instead.
+__device__ __forceinline__ int64_t xcd_contiguous_block() {
+    const unsigned b = blockIdx.x, nwg = gridDim.x, xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (int64_t)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3));
+}
 __global__ __launch_bounds__(WG) void k_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                    float *__restrict__ obs_out, float *__restrict__ ag_out,
                                                    float *__restrict__ dg_out) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (n > P.coop_limit) return;
-    const int64_t i0 = (int64_t)blockIdx.x * COOP_ENVS;
+    // a reset list covers the front of a grid sized for coop_limit entries: the remap would pile its workgroups on one or
+    // two XCDs, and the listed envs are scattered anyway - only the full-batch reset (no list) is remapped
+    const int64_t i0 = (list ? (int64_t)blockIdx.x : xcd_contiguous_block()) * COOP_ENVS;
     if (i0 >= n) return;
     const int64_t i_raw = i0 + threadIdx.x / xc::GL;
     const bool live = i_raw < n;
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(WG) void k_step_coop(KParams P, const float *__rest
                                                   int *__restrict__ stale_count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     if (blockIdx.x == 0 && threadIdx.x == 0 && stale_count) *stale_count = 0;
-    const int64_t e_raw = (int64_t)blockIdx.x * COOP_ENVS + threadIdx.x / xc::GL;
+    const int64_t e_raw = xcd_contiguous_block() * COOP_ENVS + threadIdx.x / xc::GL;
     const bool live = e_raw < P.num_envs;
     const int64_t e_in = live ? e_raw : P.num_envs - 1;
     const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
@@ -380,12 +391,73 @@ __global__ __launch_bounds__(WG) void k_reach_reset(KParams P, const int *__rest
                                                     float *__restrict__ dg_out) {
     const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
     const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n <= P.coop_limit) return;          // k_reach_reset_coop's range
     if (i >= n) return;
     const int64_t e = list ? (int64_t)list[i] : i;
     xr::EnvState<float> s;
     reach_load(P, e, s);
     float obs[xr::OBS_DIM];
     xr::env_reset<float>(P.rcfg, e, s, obs);
+    reach_store(P, e, s);
+    if (obs_out) reach_write_obs(obs, s, e, obs_out, ag_out, dg_out);
+}
+// XarmReach-v0 with one environment per DPP row of 16 lanes (xarm_reach_coop_core.h): lane l = body l = dof l.  At the
+// BASELINE size (4 096 envs) the one-env-per-lane kernels above fill 64 of 1 024 SIMDs; these fill all of them and halve
+// the dependent instructions of a substep.  Same outputs and done list.
+__global__ __launch_bounds__(WG) void k_reach_step_coop(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                        float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                        int *__restrict__ done_list, int *__restrict__ done_count,
+                                                        int *__restrict__ stale_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stale_count) *stale_count = 0;
+    const int64_t e_raw = xcd_contiguous_block() * COOP_ENVS + threadIdx.x / xc::GL;
+    const bool live = e_raw < P.num_envs;
+    const int64_t e = live ? e_raw : P.num_envs - 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    xr::EnvState<float> s;
+    reach_load(P, e, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xr::OBS_DIM], reward;
+    bool done, success;
+    int fut;
+    xrc::env_step<float>(G, P.rcfg, s, act, obs, reward, done, success, fut);
+    if (!live || G.l != 0) return;
+    reach_store(P, e, s);
+    reach_write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = done ? 1 : 0;
+    succ_out[e] = success ? 1 : 0;
+    if (done && P.auto_reset) {
+        if (term_obs) {
+            float4 *o = reinterpret_cast<float4 *>(term_obs + e * xr::OBS_DIM);
+            o[0] = make_float4(obs[0], obs[1], obs[2], obs[3]);
+            o[1] = make_float4(obs[4], obs[5], obs[6], obs[7]);
+        }
+        const int pos = atomicAdd(done_count, 1);
+        done_list[pos] = (int)e;
+    }
+}
+__global__ __launch_bounds__(WG) void k_reach_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                         float *__restrict__ obs_out, float *__restrict__ ag_out,
+                                                         float *__restrict__ dg_out) {
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n > P.coop_limit) return;
+    // a reset list covers the front of a grid sized for coop_limit entries: the remap would pile its workgroups on one or
+    // two XCDs, and the listed envs are scattered anyway - only the full-batch reset (no list) is remapped
+    const int64_t i0 = (list ? (int64_t)blockIdx.x : xcd_contiguous_block()) * COOP_ENVS;
+    if (i0 >= n) return;
+    const int64_t i_raw = i0 + threadIdx.x / xc::GL;
+    const bool live = i_raw < n;
+    const int64_t i = live ? i_raw : n - 1;
+    const int64_t e = list ? (int64_t)list[i] : i;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    xr::EnvState<float> s;
+    reach_load(P, e, s);
+    float obs[xr::OBS_DIM];
+    xrc::env_reset<float>(G, P.rcfg, e, s, obs);
+    if (!live || G.l != 0) return;
     reach_store(P, e, s);
     if (obs_out) reach_write_obs(obs, s, e, obs_out, ag_out, dg_out);
 }
@@ -710,6 +782,14 @@ static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, con
     else k_ho_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
 }
 
+static void launch_reach_reset(xarm_handle *h, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev, hipStream_t st) {
+    const int64_t cap = h->kp.num_envs < (int64_t)h->kp.coop_limit ? h->kp.num_envs : (int64_t)h->kp.coop_limit;
+    if (cap > 0)
+        k_reach_reset_coop<<<dim3((unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    if (h->kp.num_envs > cap)
+        k_reach_reset<<<dim3((unsigned)(h->kp.stride / WG)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+}
+
 // PickAndPlace reset of the envs in list[0 .. *count) (null: all): the cooperative kernel takes counts up to
 // kp.coop_limit, the one-env-per-lane kernel the rest; both are launched, the one out of its range exits at once.
 static void launch_pnp_reset(xarm_handle *h, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
@@ -789,18 +869,18 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.auto_reset = cfg->auto_reset;
     // cooperative reset kernel (PickAndPlace): default cross-over measured on MI355X; 0 disables it
     h->kp.coop_limit = 0;
-    if (cfg->env_kind == XARM_ENV_PICK_AND_PLACE) {
+    if (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH) {
         h->kp.coop_limit = cfg->reset_coop_limit > 0 ? cfg->reset_coop_limit : (cfg->reset_coop_limit < 0 ? 0 : XARM_RESET_COOP_LIMIT_DEFAULT);
         const char *ev = getenv("XARM_RESET_COOP_LIMIT");
         if (ev && *ev) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
     // cooperative step kernel: pays while the one-env-per-lane launch would leave SIMDs empty (measured cross-over,
     // DESIGN.md 5); XARM_STEP_COOP_LIMIT overrides, 0 disables
-    h->coop_step_limit = cfg->env_kind != XARM_ENV_PICK_AND_PLACE || cfg->step_coop_limit < 0 ? 0 :
+    h->coop_step_limit = (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && cfg->env_kind != XARM_ENV_REACH) || cfg->step_coop_limit < 0 ? 0 :
                          (cfg->step_coop_limit > 0 ? cfg->step_coop_limit : XARM_STEP_COOP_LIMIT_DEFAULT);
     {
         const char *ev = getenv("XARM_STEP_COOP_LIMIT");
-        if (ev && *ev && cfg->env_kind == XARM_ENV_PICK_AND_PLACE) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+        if (ev && *ev && (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH)) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
     h->kp.hcfg.seed = cfg->seed;
@@ -874,12 +954,12 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
     if (mask_dev) {
         HIPCHK(h, hipMemsetAsync(h->mask_count, 0, sizeof(int), st));
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
-        if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        if (h->cfg.env_kind == XARM_ENV_REACH) launch_reach_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
     } else {
-        if (h->cfg.env_kind == XARM_ENV_REACH) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        if (h->cfg.env_kind == XARM_ENV_REACH) launch_reach_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
@@ -918,6 +998,9 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else if (handover)
         k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
                                                                       success_dev, terminal_obs_dev, h->done_list, cnt, stale);
+    else if (reach && h->kp.num_envs <= (int64_t)h->coop_step_limit)
+        k_reach_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, stale);
     else if (reach)
         k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                       terminal_obs_dev, h->done_list, cnt, stale);
@@ -929,7 +1012,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                 terminal_obs_dev, h->done_list, cnt, stale);
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
     if (h->kp.auto_reset) {
-        if (reach) k_reach_reset<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        if (reach) launch_reach_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (handover) launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
         else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
@@ -1039,6 +1122,12 @@ int xarm_timing_read_reset(xarm_handle *h, double *reset_ms_total, int64_t *laun
     timing_flush(h);
     *reset_ms_total = h->ev_reset_ms;
     *launches = h->ev_launches;
+    return XARM_OK;
+}
+int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit) {
+    if (!h || !reset_coop_limit || !step_coop_limit) return XARM_E_INVALID;
+    *reset_coop_limit = h->kp.coop_limit;
+    *step_coop_limit = h->coop_step_limit;
     return XARM_OK;
 }
 

@@ -271,6 +271,12 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, self._L.xarm_timing_read_reset(self._h, C.byref(ms), C.byref(n)), "xarm_timing_read_reset")
         return ms.value, n.value
 
+    def kernel_limits(self):
+        """(reset_coop_limit, step_coop_limit) in force: at most that many envs run on the cooperative kernels"""
+        r, s = C.c_int32(0), C.c_int32(0)
+        _native.check(self._L, self._h, self._L.xarm_kernel_limits(self._h, C.byref(r), C.byref(s)), "xarm_kernel_limits")
+        return r.value, s.value
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._L.xarm_destroy(self._h)
@@ -304,7 +310,8 @@ class XarmReachVecEnv(XarmPickAndPlaceVecEnv):
     def _native_config(self):
         return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 0,
                                   _native.REACH_REWARD_TYPES[self.config["reward_type"]], 0, 0.0, 0.0, int(self._auto_reset),
-                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0, 0)
+                                  self.device.index if self.device.index is not None else torch.cuda.current_device(), 0.0,
+                                  int(self._reset_coop_limit), int(self._step_coop_limit), 0)
 
     def _extra_info(self, info):
         # with auto-reset, finished envs already report the fresh episode's counter

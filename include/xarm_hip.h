@@ -81,9 +81,9 @@ typedef struct xarm_config {
                                VecEnv semantics); XARM_AUTO_RESET_LAZY: see below */
     int32_t device;         /* HIP device ordinal */
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
-    int32_t reset_coop_limit; /* PickAndPlace: resets of at most this many envs per call run on the cooperative
+    int32_t reset_coop_limit; /* PickAndPlace, Reach: resets of at most this many envs per call run on the cooperative
                                (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
-    int32_t step_coop_limit;  /* PickAndPlace: a handle of at most this many envs also STEPS on the cooperative kernel
+    int32_t step_coop_limit;  /* PickAndPlace, Reach: a handle of at most this many envs also STEPS on the cooperative kernel
                                  (the one-env-per-lane launch would leave most SIMDs without a wavefront);
                                  0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never */
     int32_t use_stand;        /* XarmHandover config['use_stand'] (xarm_handover.py:391-392): a static 0.07 x 0.06 x 0.01 box
@@ -137,6 +137,10 @@ int xarm_timing_enable(xarm_handle *h, int32_t enable);
 int xarm_timing_read(xarm_handle *h, double *step_kernel_ms_total, int64_t *launches);
 /* same for the reset kernels that follow the step kernel inside xarm_step (auto_reset): total ms over `launches` calls */
 int xarm_timing_read_reset(xarm_handle *h, double *reset_kernels_ms_total, int64_t *launches);
+
+/* the limits in force for this handle after defaults and the XARM_RESET_COOP_LIMIT / XARM_STEP_COOP_LIMIT environment
+ * overrides: batches / reset lists of at most that many envs run on the cooperative kernels (0: never) */
+int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit);
 
 const char *xarm_last_error(const xarm_handle *h);
 const char *xarm_version(void);

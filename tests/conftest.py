@@ -48,7 +48,7 @@ class HostCore:
         so = os.path.join(d, "libxarm_host.so")
         srcs = [os.path.join(d, "xarm_host.cpp")] + [os.path.join(ROOT, "gym_xarm_amd", "csrc", f) for f in (
             "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_stack_core.h",
-            "xarm_coop_core.h")]
+            "xarm_coop_core.h", "xarm_reach_coop_core.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
                                    "-o", so, srcs[0]])
@@ -134,23 +134,24 @@ class HostCore:
         self.L.xh_reach_init(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st))
         return st
 
-    def reach_step(self, state, actions, f32=1, seed=0, off=0, rt=0):
+    def reach_step(self, state, actions, f32=1, seed=0, off=0, rt=0, coop=False):
+        """coop=True: the 16-lanes-per-env core (csrc/xarm_reach_coop_core.h)"""
         E = state.shape[0]
         st = np.array(state, dtype=np.float64, copy=True)
         a = np.ascontiguousarray(actions, dtype=np.float64)
         obs, ag, dg = np.zeros((E, 8)), np.zeros((E, 3)), np.zeros((E, 3))
         rew, done, succ, fut = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.zeros(E, np.int32)
-        self.L.xh_reach_step(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), self._p(a),
+        (self.L.xh_reach_coop_step if coop else self.L.xh_reach_step)(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), self._p(a),
                              self._p(obs), self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ),
                              fut.ctypes.data_as(C.POINTER(C.c_int32)))
         return st, obs, ag, dg, rew, done, succ, fut
 
-    def reach_reset(self, state, mask=None, f32=1, seed=0, off=0, rt=0):
+    def reach_reset(self, state, mask=None, f32=1, seed=0, off=0, rt=0, coop=False):
         E = state.shape[0]
         st = np.array(state, dtype=np.float64, copy=True)
         obs, ag, dg = np.zeros((E, 8)), np.zeros((E, 3)), np.zeros((E, 3))
         mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
-        self.L.xh_reach_reset(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), mk,
+        (self.L.xh_reach_coop_reset if coop else self.L.xh_reach_reset)(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_int(rt), C.c_int64(E), self._p(st), mk,
                               self._p(obs), self._p(ag), self._p(dg))
         return st, obs, ag, dg
 

@@ -10,6 +10,7 @@
 #include "../../gym_xarm_amd/csrc/xarm_handover_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_stack_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_coop_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_reach_coop_core.h"
 #include <pthread.h>
 #include <string.h>
 
@@ -149,6 +150,29 @@ template <typename T> void rstore(const xr::EnvState<T> &s, double *r) {
     for (int i = 0; i < 3; i++) r[xr::R_GOAL + i] = s.goal[i];
     r[xr::R_DOLD] = s.d_old; r[xr::R_STEPS] = s.steps; r[xr::R_EPISODE] = s.episode;
 }
+template <typename T> void reach_coop_step(const xr::EnvCfg &c, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
+    for (int64_t e = 0; e < E; e++) {
+        xr::EnvState<T> s; rload(state + e * xr::STATE_DIM, s);
+        T a[4], o[xr::OBS_DIM], r; bool d, su; int f;
+        for (int k = 0; k < 4; k++) a[k] = (T)act[e * 4 + k];
+        xrc::env_step<T>(xc::Grp(), c, s, a, o, r, d, su, f);
+        rstore(s, state + e * xr::STATE_DIM);
+        for (int k = 0; k < 8; k++) obs[e * 8 + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = o[k]; dg[e * 3 + k] = s.goal[k]; }
+        rew[e] = r; done[e] = d; succ[e] = su; fut[e] = f;
+    }
+}
+template <typename T> void reach_coop_reset(const xr::EnvCfg &c, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    for (int64_t e = 0; e < E; e++) {
+        if (mask && !mask[e]) continue;
+        xr::EnvState<T> s; rload(state + e * xr::STATE_DIM, s);
+        T o[xr::OBS_DIM];
+        xrc::env_reset<T>(xc::Grp(), c, e, s, o);
+        rstore(s, state + e * xr::STATE_DIM);
+        for (int k = 0; k < 8; k++) obs[e * 8 + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = o[k]; dg[e * 3 + k] = s.goal[k]; }
+    }
+}
 template <typename T> void reach_step(const xr::EnvCfg &c, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
     for (int64_t e = 0; e < E; e++) {
         xr::EnvState<T> s; rload(state + e * xr::STATE_DIM, s);
@@ -283,6 +307,14 @@ void xh_reach_init(int f32, uint64_t seed, int64_t off, int rt, int64_t E, doubl
 void xh_reach_step(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
     auto c = rcfg(seed, off, rt);
     if (f32) reach_step<float>(c, E, state, act, obs, ag, dg, rew, done, succ, fut); else reach_step<double>(c, E, state, act, obs, ag, dg, rew, done, succ, fut);
+}
+void xh_reach_coop_step(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, int32_t *fut) {
+    auto c = rcfg(seed, off, rt);
+    if (f32) reach_coop_step<float>(c, E, state, act, obs, ag, dg, rew, done, succ, fut); else reach_coop_step<double>(c, E, state, act, obs, ag, dg, rew, done, succ, fut);
+}
+void xh_reach_coop_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = rcfg(seed, off, rt);
+    if (f32) reach_coop_reset<float>(c, E, state, mask, obs, ag, dg); else reach_coop_reset<double>(c, E, state, mask, obs, ag, dg);
 }
 void xh_reach_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
     auto c = rcfg(seed, off, rt);

@@ -112,15 +112,18 @@ def test_reach_model_matches_urdf(oracle):
     assert names.index("left_outer_knuckle") + 1 == 10 and len(names) + 1 == 17    # gripper_driver_index, num_joints (:21-22)
 
 
-def test_hostcore_f64_equals_oracle(hostcore, groll):
+@pytest.mark.parametrize("coop", [False, True], ids=["lane", "coop"])
+def test_hostcore_f64_equals_oracle(hostcore, groll, coop):
+    """both kernel families' cores (one env per lane: xarm_reach_core.h; one env per 16-lane row:
+    xarm_reach_coop_core.h) instantiated in float64 on the host reproduce the oracle"""
     g = groll
     st = hostcore.reach_init(32, f32=0, seed=3)
     np.testing.assert_allclose(st, g["init_state"], atol=1e-15)
-    st, obs, ag, dg = hostcore.reach_reset(st, f32=0, seed=3)
+    st, obs, ag, dg = hostcore.reach_reset(st, f32=0, seed=3, coop=coop)
     np.testing.assert_allclose(st, g["states"][0], atol=1e-10)
     np.testing.assert_allclose(obs, g["reset_obs"], atol=1e-10)
     for t in range(g["actions"].shape[0]):
-        st, obs, ag, dg, rew, done, succ, fut = hostcore.reach_step(g["states"][t], g["actions"][t], f32=0, seed=3)
+        st, obs, ag, dg, rew, done, succ, fut = hostcore.reach_step(g["states"][t], g["actions"][t], f32=0, seed=3, coop=coop)
         ok = g["sens"][t] < 1e-3
         np.testing.assert_allclose(st[ok, :7], g["states"][t + 1][ok, :7], atol=1e-8)
         np.testing.assert_allclose(obs[ok][:, :7], g["obs"][t][ok][:, :7], atol=1e-6)
@@ -128,10 +131,11 @@ def test_hostcore_f64_equals_oracle(hostcore, groll):
         assert ok.mean() > 0.7
 
 
-def test_hostcore_f32_within_tolerance(hostcore, groll):
+@pytest.mark.parametrize("coop", [False, True], ids=["lane", "coop"])
+def test_hostcore_f32_within_tolerance(hostcore, groll, coop):
     g = groll
     for t in range(g["actions"].shape[0]):
-        st, obs, ag, dg, rew, done, succ, fut = hostcore.reach_step(g["states"][t], g["actions"][t], f32=1, seed=3)
+        st, obs, ag, dg, rew, done, succ, fut = hostcore.reach_step(g["states"][t], g["actions"][t], f32=1, seed=3, coop=coop)
         check_obs(obs, g["obs"][t], g["sens"][t], "f32 host t=%d" % t)
         ok = g["sens"][t] < 1e-3
         np.testing.assert_allclose(st[ok, :7], g["states"][t + 1][ok, :7], atol=1e-4)
@@ -139,13 +143,19 @@ def test_hostcore_f32_within_tolerance(hostcore, groll):
 
 
 # ------------------------------------------------------------------------------------------- GPU
+# kernel families: "lane" = k_reach_step / k_reach_reset (one env per lane), "coop" = k_reach_step_coop /
+# k_reach_reset_coop (one env per DPP row); the limits force one or the other whatever the batch size
+FAMILY = {"lane": dict(reset_coop_limit=-1, step_coop_limit=-1), "coop": dict(reset_coop_limit=1 << 30, step_coop_limit=1 << 30)}
+
+
 @pytest.mark.gpu
-def test_gpu_reach_replays_golden_rollout(groll):
+@pytest.mark.parametrize("family", ["lane", "coop"])
+def test_gpu_reach_replays_golden_rollout(groll, family):
     import torch
     import gym_xarm_amd as gx
     g = groll
     E = g["states"].shape[1]
-    env = gx.make("XarmReach-v0", num_envs=E, seed=3, auto_reset=False)
+    env = gx.make("XarmReach-v0", num_envs=E, seed=3, auto_reset=False, **FAMILY[family])
     np.testing.assert_allclose(env.get_state().cpu().numpy(), g["init_state"], atol=1e-6)
     obs = env.reset()
     np.testing.assert_allclose(obs["observation"].cpu().numpy()[:, :3], g["reset_obs"][:, :3], atol=1e-4)
@@ -167,12 +177,13 @@ def test_gpu_reach_replays_golden_rollout(groll):
 
 
 @pytest.mark.gpu
-def test_gpu_reach_4096_episode_and_registry(gref):
+@pytest.mark.parametrize("family", ["lane", "coop", "default"])
+def test_gpu_reach_4096_episode_and_registry(gref, family):
     """BASELINE config 2: XarmReach-v0, 4096 envs on one GPU; plus the reference's test.py pattern"""
     import torch
     import gym_xarm_amd as gx
     E = 4096
-    env = gx.make("XarmReach-v0", num_envs=E, seed=0, config={"reward_type": "dense", "GUI": False})
+    env = gx.make("XarmReach-v0", num_envs=E, seed=0, config={"reward_type": "dense", "GUI": False}, **FAMILY.get(family, {}))
     obs = env.reset()
     dg = obs["desired_goal"].clone()
     for k in range(25):

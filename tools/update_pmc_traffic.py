@@ -22,8 +22,8 @@ def main():
     t = json.load(open(out)) if os.path.exists(out) else (json.load(open(base)) if os.path.exists(base) else {})
     for role, names in (("step", STEP_KERNEL), ("reset", RESET_KERNEL)):
         k = names[wl]
-        if wl == "pnp" and role == "step" and "k_step_coop" in d and "k_step" not in d:
-            k = "k_step_coop"
+        if k not in d and k + "_coop" in d:      # the cooperative family served this batch size (pnp, reach)
+            k = k + "_coop"
         if k not in d or "FETCH_SIZE" not in d[k] or "WRITE_SIZE" not in d[k]:
             continue
         hbm = (2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024

@@ -37,7 +37,10 @@ class XarmPickAndPlaceVecEnv:
         cfg = dict(CONFIG_DEFAULTS)
         cfg.update(config or {})
         if cfg["num_obj"] != 1:
-            raise NotImplementedError("this build supports num_obj == 1")
+            # not runnable in the reference either: step() -> _is_success (xarm_pick_and_place.py:114, :289-291) subtracts
+            # self.goal of shape (N, 3) from the flat achieved_goal of shape (3N,), a NumPy broadcast error for N > 1
+            raise NotImplementedError("XarmPickAndPlace supports num_obj == 1 only (with num_obj > 1 the reference's own "
+                                      "step() raises a broadcast ValueError in _is_success, xarm_pick_and_place.py:289-291)")
         if cfg["reward_type"] not in _native.REWARD_TYPES:
             # 'dense_diff_o2g' / 'incremental' raise in the reference itself (:179, :302-308)
             raise NotImplementedError("reward_type %r" % (cfg["reward_type"],))

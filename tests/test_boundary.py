@@ -61,6 +61,21 @@ def test_no_device_errors_are_reported_not_thrown(lib):
     assert L.xarm_destroy(None) == 0 and L.xarm_step(None, *([None] * 9)) == -1
 
 
+def test_pnp_num_obj_above_one_is_a_broadcast_error_in_the_reference():
+    """XarmPickAndPlace.step -> _is_success (xarm_pick_and_place.py:114, :289-291) evaluates
+    `np.linalg.norm(achieved_goal - self.goal, axis=-1)` with achieved_goal flat (3N,) (`_get_obs` :239) and self.goal
+    (N, 3) (`_sample_goal` returns np.array(goal), :287): defined for N = 1 only.  The VecEnv therefore refuses
+    num_obj > 1 for PickAndPlace instead of inventing a behaviour."""
+    import numpy as np
+    assert np.linalg.norm(np.zeros(3) - np.zeros((1, 3)), axis=-1).shape == (1,)
+    for n in (2, 3, 4):
+        with pytest.raises(ValueError):
+            np.zeros(3 * n) - np.zeros((n, 3))
+    from gym_xarm_amd.vec_env import XarmPickAndPlaceVecEnv
+    with pytest.raises(NotImplementedError, match="broadcast"):
+        XarmPickAndPlaceVecEnv._check_config(None, {"num_obj": 2})
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "gym_xarm_amd")
     for dp, _, files in os.walk(pkg):

@@ -457,6 +457,9 @@ XARM_HD LV<T> row_impulse(const Grp &G, Sweep<T> &W, T mu) {
 // G (gear), F (pad points).  The table rows never couple to the single-joint rows (A is block diagonal there; only
 // the pad rows touch both), so table row i and single-joint row i - both owned by lane i - are advanced in one PAIR
 // step on packed registers: same arithmetic per row, same order within each block, 14 steps instead of 26.
+#ifndef XC_SWEEP_ITERS
+#define XC_SWEEP_ITERS xm::NUM_ITERATIONS   // timing probes only (tools/coop_split.sh) build with fewer sweeps
+#endif
 template <typename T, bool PAD, bool LA>
 XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&padw)[NP]) {
     LV2<T> g01 = lv2_make(W.g[0], W.g[1]), lam01 = lv2_make(W.lam[0], W.lam[1]), invd01 = lv2_make(W.invd[0], W.invd[1]);
@@ -469,7 +472,7 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
     }
     const LV<T> mu_tv = lv_fill(mu_t);
 #pragma unroll 1
-    for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+    for (int it = 0; it < XC_SWEEP_ITERS; it++) {
         LV<T> lim = lv_fill((T)0);
         // pair step i: table row i (normal of point i/3 when i % 3 == 0, else friction; none for i >= 12) + slot-1 row i
 #define XC_PAIR(i)                                                                                           \

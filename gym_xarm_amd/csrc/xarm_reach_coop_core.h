@@ -282,7 +282,7 @@ template <typename T> XARM_HD void substep(const Grp &G, const BodyLane<T> &C, E
 #undef XRC_LIMW
     const LV<T> mhi = lv_fill(m_hi), mlo = lv_fill(-m_hi);
 #pragma unroll 1
-    for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+    for (int it = 0; it < XC_SWEEP_ITERS; it++) {
 #define XRC_MOTOR(r)                                                                                         \
         {                                                                                                    \
             const LV<T> lam = xc::lv2_x(lam01);                                                              \

@@ -65,7 +65,7 @@ def reference_availability():
         import pybullet  # noqa: F401
     except Exception as e:   # ModuleNotFoundError on every box of this project so far
         return "unavailable (pybullet not importable: %s)" % type(e).__name__
-    return "pybullet importable - side-by-side harness: tools/pybullet_harness.py (not run by bench.py)"
+    return "pybullet importable - side-by-side harness: tests/tools/pybullet_harness.py (not run by bench.py)"
 
 
 def cpu_baseline(workload="pnp"):
@@ -217,11 +217,42 @@ def main():
     order = sorted(range(len(windows)), key=lambda k: windows[k][0])
     dt, resets, kstep_ms, reset_ms, launches = windows[order[len(order) // 2]]     # the median window
 
+    # extra (workloads measured with desynchronised phases): the same env started in lockstep - every episode from
+    # reset() together, the time-limit resets arriving as one bulk reset every T_ep-th step, which is what a caller sees
+    # until early successes spread the phases.  Never feeds `value`; timed over whole episodes (>= 2 * T_ep steps) so
+    # that the window holds its share of bulk resets whatever --steps is.
+    lockstep = None
+    if args.episode_phase == "desync" and not args.no_lazy and hasattr(env, "set_episode_steps"):
+        env.close()
+        kenv = make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config)
+        kenv.reset()
+        for i in range(args.warmup):
+            kenv.step(ring[i % 64])
+        n_lock = 2 * T_ep
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n_lock):
+            kenv.step(ring[(args.warmup + i) % 64])
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        kdt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        lockstep = {"value": int(D.sum_over_ranks(E, device=dev)) * n_lock / kdt, "unit": "env steps/s", "steps": n_lock,
+                    "ms_per_step": kdt / n_lock * 1e3,
+                    "note": "episodes in lockstep from reset(): bulk resets every %d-th step instead of E/%d per step; "
+                            "`value` is the desynchronised steady state, the slower of the two" % (T_ep, T_ep)}
+        kenv.close()
+        env = None
+
     # extra (pnp only): the opt-in lazy auto-reset mode (include/xarm_hip.h XARM_AUTO_RESET_LAZY) - a different contract
     # from the reference's VecEnv, so it never feeds `value`; useful = env steps that are not reset ticks
     lazy = None
     if args.workload == "pnp" and not args.no_lazy:
-        env.close()
+        if env is not None:
+            env.close()
         lenv = make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config, auto_reset="lazy")
         lenv.reset()
         useful = torch.zeros((), device=dev)
@@ -313,6 +344,8 @@ def main():
         }
         if valu is not None:
             out["roofline"]["valu"] = valu
+        if lockstep is not None:
+            out["lockstep_phase"] = lockstep
         if lazy is not None:
             out["lazy_reset"] = lazy
         if world == 1 and not args.no_cpu_baseline:

@@ -84,6 +84,12 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dp, f)).read()
                 code = "\n".join(l for l in text.split("\n") if not l.strip().startswith(("//", "#", "*", "/*")))
                 assert not re.search(r"(from|import)\s+oracle|libxarm_oracle|xarm_oracle\.h|hostbuild", code), f
+    # the development tools measure and generate for the product: those that need the oracle live under tests/tools/
+    for dp, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh", ".cpp", ".hip")):
+                code = open(os.path.join(dp, f)).read()
+                assert not re.search(r"(from|import)\s+oracle\b|libxarm_oracle|xarm_oracle\.h", code), f
 
 
 def test_registry_and_spaces_mirror_reference():

@@ -108,7 +108,9 @@ def test_bench_rank_plumbing_two_ranks_gloo(tmp_path, scaling):
     else:
         assert d["config"]["total_envs"] == 101 and [s[0]["num_envs"] for s in shards] == [51, 50]      # shard_range
         assert [s[0]["env_id_offset"] for s in shards] == [0, 51]
-    assert all(s[1]["auto_reset"] == "lazy" for s in shards)                                             # the lazy leg ran too
+    assert all(s[1]["auto_reset"] == "True" and s[1]["num_envs"] == s[0]["num_envs"] for s in shards)      # the lockstep-phase leg
+    assert all(s[2]["auto_reset"] == "lazy" for s in shards)                                             # the lazy leg ran too
+    assert d["lockstep_phase"]["steps"] == 20 and d["lockstep_phase"]["value"] > 0
     assert abs(d["value"] - d["config"]["total_envs"] * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
     assert len(d["repeats"]["env_steps_per_sec"]) == 2 and d["repeats"]["min"] <= d["value"] <= d["repeats"]["max"]
     assert d["roofline"]["kernels"]["reset"]["avg_ms"] == 0.25 and abs(d["roofline"]["kernel_avg_ms"] - 0.75) < 1e-9

@@ -386,12 +386,12 @@ def test_rollout_statistics_match_oracle(gxk, oracle):
 
 def test_contact_regime_256_envs(gxk, oracle, parity):
     """The grasp / contact regime with a fixture that bites: 256 envs under the scripted reach-grasp-lift with per-env
-    jitter (tools/gen_oracle_fixtures.JitteredGrasp), every transition replayed on the device from the oracle's
+    jitter (tests/tools/gen_oracle_fixtures.JitteredGrasp), every transition replayed on the device from the oracle's
     state.  Thresholds are what the kernels achieve, not what they are allowed: >= 90 % of the envs inside the plain
     5e-4 + 2e-4|x| bound at EVERY step, <= 10 % exempt (sens > 0.05), the allowance of the rest capped at 1e-2, and the
     rows that are in contact (pad impulses / touch flag) held to the same numbers separately."""
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     from gen_oracle_fixtures import JitteredGrasp
     E = 256
     ora = oracle.OraclePnP(E, seed=61)

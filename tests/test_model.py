@@ -119,6 +119,6 @@ def test_primitives_urdf_round_trips_the_model_table():
 def test_pybullet_harness_reports_unavailable_cleanly():
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pybullet_harness.py")], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "pybullet_harness.py")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
     assert out.stdout.startswith("reference: unavailable (pybullet not importable") or out.stdout.startswith("reference: pybullet")

@@ -3,7 +3,7 @@ of XarmPDPickAndPlace-v0 from the same seeds and actions, through episode bounda
 hold the smaller versions)."""
 import sys, os, time
 from concurrent.futures import ThreadPoolExecutor
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, gym_xarm_amd
 from oracle import oracle as O
 E, T, W = 8192, 60, 16

@@ -2,7 +2,7 @@
 """Emit a primitives-only URDF of the model the kernels simulate (gym_xarm_amd/model/xarm7_pd.json) - SURVEY.md 7
 steps 1 and 8: PyBullet, where it is available, can then simulate the IDENTICAL model (same joint frames, masses,
 inertias, and the build's collision primitives: two pad spheres per finger, no arm / hand collision geometry) side by
-side with the kernels (tools/pybullet_harness.py).  Nothing here reads the reference's URDF or meshes; the numbers
+side with the kernels (tests/tools/pybullet_harness.py).  Nothing here reads the reference's URDF or meshes; the numbers
 come from the model table, whose entries cite them.
 
   python tools/emit_primitives_urdf.py [out.urdf]

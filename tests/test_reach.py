@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # obs: hand COM pos 3, hand COM vel 3, driver q, driver qd
 OBS_ATOL = np.array([1e-4] * 3 + [2e-2] * 3 + [5e-3, 60.0])
 K_SENS = 300.0
@@ -212,6 +213,46 @@ def test_gpu_reach_4096_episode_and_registry(gref, family):
         if d:
             ob = one.reset()
     one.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reach_kernel_families_agree_and_limits():
+    """the two kernel families step the same 4 096 envs through a whole episode + auto-reset and stay together
+    (observable part of the state; the gripper joint rates are chaotic); `kernel_limits` reports what
+    the handle runs on: default 8 192 / 8 192, < 0 = never, the environment variables override"""
+    import subprocess
+    import sys
+    import torch
+    import gym_xarm_amd as gx
+    E = 4096
+    envs = {f: gx.make("XarmReach-v0", num_envs=E, seed=9, config={"reward_type": "dense", "GUI": False}, **FAMILY[f]) for f in ("lane", "coop")}
+    assert envs["lane"].kernel_limits() == (0, 0) and envs["coop"].kernel_limits() == (1 << 30, 1 << 30)
+    obs = {f: e.reset() for f, e in envs.items()}
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    worst = worst_v = 0.0
+    for t in range(30):
+        a = torch.rand(E, 4, device="cuda", generator=gen) * 2 - 1
+        out = {f: e.step(a) for f, e in envs.items()}
+        (ol, rl, dl, il), (oc, rc, dc, ic) = out["lane"], out["coop"]
+        assert torch.equal(dl, dc) and torch.equal(il["future_length"], ic["future_length"])
+        assert torch.equal(ol["desired_goal"], oc["desired_goal"])                 # same RNG stream through the reset
+        d = (ol["observation"][:, :3] - oc["observation"][:, :3]).abs().max().item()
+        worst = max(worst, d)
+        dv = (ol["observation"][:, 3:6] - oc["observation"][:, 3:6]).abs().max(dim=1).values
+        worst_v = max(worst_v, torch.quantile(dv, 0.99).item())
+        assert (rl - rc).abs().max().item() < 2e-3
+    # free-running: the hand position stays together; the hand velocity feels the chaotic gripper joints
+    print("lane vs coop Reach kernels over 30 steps: worst |d hand pos| = %.2e, 99 %% quantile of |d hand vel| <= %.2e" % (worst, worst_v))
+    assert worst < 5e-3 and worst_v < 0.2     # measured on MI355X: 1.6e-3 m, 6.8e-2 m/s
+    for e in envs.values():
+        e.close()
+    d = gx.make("XarmReach-v0", num_envs=8)
+    assert d.kernel_limits() == (8192, 8192)
+    d.close()
+    code = ("import gym_xarm_amd as gx; e = gx.make('XarmReach-v0', num_envs=8); print(e.kernel_limits()); e.close()")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, XARM_RESET_COOP_LIMIT="0", XARM_STEP_COOP_LIMIT="123", PYTHONPATH=ROOT))
+    assert out.returncode == 0 and "(0, 123)" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu

@@ -58,6 +58,12 @@ XARM_HD int lane_of(const Grp &, int i) { return i; }
 template <typename T> struct LV { T v[LVN]; };
 #define XC_LANES for (int i_ = 0; i_ < LVN; i_++)
 template <typename T> XARM_HD LV<T> lv_fill(T u) { LV<T> r; XC_LANES r.v[i_] = u; return r; }
+// a compile-time constant held in a VGPR (an inline constant cannot be the DPP operand of v_mul_f32_dpp)
+#if defined(__HIPCC__) && !defined(XARM_HOST_BUILD)
+XARM_HD LV<float> lv_fill_vgpr(float u) { LV<float> r; r.v[0] = u; asm volatile("" : "+v"(r.v[0])); return r; }
+#else
+template <typename T> XARM_HD LV<T> lv_fill_vgpr(T u) { return lv_fill(u); }
+#endif
 // one fused multiply-add, never a separately rounded product: the sweep must round identically in every
 // instantiation (the row set is chosen per wavefront, an environment's result must not depend on its neighbours)
 XARM_HD float fm(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -150,6 +156,7 @@ XARM_HD LV<float> lv2_x(LV2<float> a) { LV<float> r; r.v[0] = a.v.x; return r; }
 XARM_HD LV<float> lv2_y(LV2<float> a) { LV<float> r; r.v[0] = a.v.y; return r; }
 XARM_HD LV2<float> lv2_fma(LV2<float> a, LV2<float> b, LV2<float> c) { LV2<float> r; r.v = __builtin_elementwise_fma(a.v, b.v, c.v); return r; }
 XARM_HD LV2<float> lv2_sub(LV2<float> a, LV2<float> b) { XC_NO_CONTRACT LV2<float> r; r.v = a.v - b.v; return r; }
+XARM_HD LV2<float> lv2_mul(LV2<float> a, LV2<float> b) { XC_NO_CONTRACT LV2<float> r; r.v = a.v * b.v; return r; }
 template <int L> XARM_HD void lv2_commit(const Grp &G, LV2<float> &dst, LV2<float> src) { dst.v = G.l == L ? src.v : dst.v; }
 template <int L> XARM_HD LV2<float> lv2_bcast(LV2<float> x) {
     LV2<float> r;
@@ -165,6 +172,7 @@ template <typename T> XARM_HD LV<T> lv2_x(LV2<T> a) { return a.x; }
 template <typename T> XARM_HD LV<T> lv2_y(LV2<T> a) { return a.y; }
 template <typename T> XARM_HD LV2<T> lv2_fma(LV2<T> a, LV2<T> b, LV2<T> c) { return lv2_make(lv_fma(a.x, b.x, c.x), lv_fma(a.y, b.y, c.y)); }
 template <typename T> XARM_HD LV2<T> lv2_sub(LV2<T> a, LV2<T> b) { return lv2_make(lv_sub(a.x, b.x), lv_sub(a.y, b.y)); }
+template <typename T> XARM_HD LV2<T> lv2_mul(LV2<T> a, LV2<T> b) { return lv2_make(lv_mul(a.x, b.x), lv_mul(a.y, b.y)); }
 template <int L, typename T> XARM_HD void lv2_commit(const Grp &G, LV2<T> &dst, LV2<T> src) { lv_commit<L>(G, dst.x, src.x); lv_commit<L>(G, dst.y, src.y); }
 template <int L, typename T> XARM_HD LV2<T> lv2_bcast(LV2<T> x) { return lv2_make(lv_bcast<L>(x.x), lv_bcast<L>(x.y)); }
 #endif
@@ -387,7 +395,6 @@ XARM_HD void lane_delassus_extra(const Setup<T> &S, int l, const T (&R)[R_N], T 
 
 // ---------------------------------------------------------------------------------------------
 // one solver row, owned by lane LANE in slot SLOT; column indices of the row in each coupled slot
-enum { K_FIXED = 0, K_NORMAL = 1, K_FRICTION = 2 };
 template <typename T> struct Sweep {
     LV<T> g[4], lam[4], invd[4];
     LV<T> lo1, hi1;
@@ -439,20 +446,6 @@ XARM_HD void pad_columns(const Grp &G, const Setup<T> &S, const LV<T> (&J)[R_G],
 #undef XC_PAD_COL
 }
 
-// one row of slot 2 (pad rows) or slot 3 (arm limits), owned by lane LANE: returns the broadcast impulse change
-template <int SLOT, int LANE, int KIND, int NLANE, typename T>
-XARM_HD LV<T> row_impulse(const Grp &G, Sweep<T> &W, T mu) {
-    LV<T> nl = lv_fma(W.g[SLOT], W.invd[SLOT], W.lam[SLOT]);
-    if (KIND == K_NORMAL) nl = lv_max0(nl);
-    else {
-        const LV<T> lim = lv_mul(lv_bcast<NLANE>(W.lam[SLOT]), lv_fill(mu));
-        nl = lv_med3(nl, lv_neg(lim), lim);
-    }
-    const LV<T> dl = lv_sub(nl, W.lam[SLOT]);
-    lv_commit<LANE>(G, W.lam[SLOT], nl);
-    return lv_bcast<LANE>(dl);
-}
-
 // The NUM_ITERATIONS sweeps.  Row order of the oracle: T (table points), M (motors), L (arm limits, finger limits),
 // G (gear), F (pad points).  The table rows never couple to the single-joint rows (A is block diagonal there; only
 // the pad rows touch both), so table row i and single-joint row i - both owned by lane i - are advanced in one PAIR
@@ -460,52 +453,105 @@ XARM_HD LV<T> row_impulse(const Grp &G, Sweep<T> &W, T mu) {
 #ifndef XC_SWEEP_ITERS
 #define XC_SWEEP_ITERS xm::NUM_ITERATIONS   // timing probes only (tools/coop_split.sh) build with fewer sweeps
 #endif
+// The loop carries c = lam + g / d per row (the unclamped impulse the row would take now) instead of the residual g:
+// a row step is then clamp(c) -> d lam -> broadcast -> c += (A / d) d lam for every other row, FOUR dependent
+// instructions where the residual form needs five (it re-derives lam + g / d first) - and the sweep is bound by exactly
+// that chain (tools/probes/dpp_probe.hip).  The columns are scaled by the receiving row's 1 / d once per substep; a
+// row's own entry becomes zero, because its c does not move when its own impulse does (lam + dl + (g - d dl) / d).
 template <typename T, bool PAD, bool LA>
 XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&padw)[NP]) {
-    LV2<T> g01 = lv2_make(W.g[0], W.g[1]), lam01 = lv2_make(W.lam[0], W.lam[1]), invd01 = lv2_make(W.invd[0], W.invd[1]);
-    LV2<T> nA01[NA1], nAF01[NF];
+    LV2<T> lam01 = lv2_make(W.lam[0], W.lam[1]);
+    const LV2<T> invd01 = lv2_make(W.invd[0], W.invd[1]), zero2 = lv2_make(lv_fill((T)0), lv_fill((T)0));
+    LV2<T> c01 = lv2_fma(lv2_make(W.g[0], W.g[1]), invd01, lam01);
+    LV2<T> A01[NA1], AF01[NF];
+#define XC_COL01(i)                                                                                          \
+    A01[i] = lv2_mul(lv2_make((i) < NT ? W.nA0[C0_T + (i)] : lv_fill((T)0), W.nA1[C1_A + (i)]), invd01);    \
+    lv2_commit<i>(G, A01[i], zero2);
+    XC_COL01(0) XC_COL01(1) XC_COL01(2) XC_COL01(3) XC_COL01(4) XC_COL01(5) XC_COL01(6) XC_COL01(7) XC_COL01(8) XC_COL01(9)
+    XC_COL01(10) XC_COL01(11) XC_COL01(12) XC_COL01(13)
+#undef XC_COL01
+    LV<T> AL1[7];   // arm-limit columns of the single-joint rows
+    if (LA) {
 #pragma unroll
-    for (int i = 0; i < NA1; i++) nA01[i] = lv2_make(i < NT ? W.nA0[C0_T + i] : lv_fill((T)0), W.nA1[C1_A + i]);
-    if (PAD) {
-#pragma unroll
-        for (int r = 0; r < NF; r++) nAF01[r] = lv2_make(W.nA0[C0_F + r], W.nA1[C1_F + r]);
+        for (int i = 0; i < 7; i++) AL1[i] = lv_mul(W.nA1[C1_L + i], W.invd[1]);
     }
-    const LV<T> mu_tv = lv_fill(mu_t);
+    LV<T> c2 = lv_fill((T)0), c3 = lv_fill((T)0);
+    if (PAD) {
+        c2 = lv_fma(W.g[2], W.invd[2], W.lam[2]);
+#pragma unroll
+        for (int i = 0; i < NT; i++) W.nA2[C2_T + i] = lv_mul(W.nA2[C2_T + i], W.invd[2]);
+#pragma unroll
+        for (int i = 0; i < NA1; i++) W.nA2[C2_A + i] = lv_mul(W.nA2[C2_A + i], W.invd[2]);
+        if (LA) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) W.nA2[C2_L + i] = lv_mul(W.nA2[C2_L + i], W.invd[2]);
+        }
+#define XC_COLF(r)                                                                                           \
+        if (padw[(r) / 3]) {                                                                                 \
+            AF01[r] = lv2_mul(lv2_make(W.nA0[C0_F + r], W.nA1[C1_F + r]), invd01);                           \
+            W.nA2[C2_F + r] = lv_mul(W.nA2[C2_F + r], W.invd[2]);                                            \
+            lv_commit<r>(G, W.nA2[C2_F + r], lv_fill((T)0));                                                 \
+            if (LA) W.nA3[C1_F + r] = lv_mul(W.nA3[C1_F + r], W.invd[3]);                                    \
+        }
+        XC_COLF(0) XC_COLF(1) XC_COLF(2) XC_COLF(3) XC_COLF(4) XC_COLF(5) XC_COLF(6) XC_COLF(7) XC_COLF(8) XC_COLF(9) XC_COLF(10) XC_COLF(11)
+#undef XC_COLF
+    }
+    if (LA) {
+        c3 = lv_fma(W.g[3], W.invd[3], W.lam[3]);
+#pragma unroll
+        for (int i = 0; i < NA1; i++) W.nA3[C1_A + i] = lv_mul(W.nA3[C1_A + i], W.invd[3]);
+#define XC_COLL(i)                                                                                           \
+        W.nA3[C1_L + i] = lv_mul(W.nA3[C1_L + i], W.invd[3]);                                                \
+        lv_commit<i>(G, W.nA3[C1_L + i], lv_fill((T)0));
+        XC_COLL(0) XC_COLL(1) XC_COLL(2) XC_COLL(3) XC_COLL(4) XC_COLL(5) XC_COLL(6)
+#undef XC_COLL
+    }
+    const LV<T> mu_tv = lv_fill_vgpr(mu_t), mu_pv = lv_fill(mu_p);
 #pragma unroll 1
     for (int it = 0; it < XC_SWEEP_ITERS; it++) {
         LV<T> lim = lv_fill((T)0);
         // pair step i: table row i (normal of point i/3 when i % 3 == 0, else friction; none for i >= 12) + slot-1 row i
 #define XC_PAIR(i)                                                                                           \
         {                                                                                                    \
-            LV2<T> nl = lv2_fma(g01, invd01, lam01);                                                         \
-            LV<T> nx = lv2_x(nl);                                                                            \
+            LV<T> nx = lv2_x(c01);                                                                           \
             if ((i) % 3 == 0 || (i) >= NT) nx = lv_max0(nx);                                                 \
             else nx = lv_med3(nx, lv_neg(lim), lim);                                                         \
-            nl = lv2_make(nx, lv_med3(lv2_y(nl), W.lo1, W.hi1));                                             \
+            const LV2<T> nl = lv2_make(nx, lv_med3(lv2_y(c01), W.lo1, W.hi1));                               \
             const LV2<T> dl = lv2_sub(nl, lam01);                                                            \
             lv2_commit<i>(G, lam01, nl);                                                                     \
             if ((i) % 3 == 0 && (i) < NT) lim = lv_mul(lv_bcast<i>(nx), mu_tv); /* friction limit of this point */ \
             const LV2<T> b = lv2_bcast<i>(dl);                                                               \
-            g01 = lv2_fma(nA01[i], b, g01);                                                                  \
+            c01 = lv2_fma(A01[i], b, c01);                                                                   \
             if (PAD) {                                                                                       \
-                if ((i) < NT) W.g[2] = lv_fma(W.nA2[C2_T + (i)], lv2_x(b), W.g[2]);                          \
-                W.g[2] = lv_fma(W.nA2[C2_A + (i)], lv2_y(b), W.g[2]);                                        \
+                if ((i) < NT) c2 = lv_fma(W.nA2[C2_T + (i)], lv2_x(b), c2);                                  \
+                c2 = lv_fma(W.nA2[C2_A + (i)], lv2_y(b), c2);                                                \
             }                                                                                                \
-            if (LA) W.g[3] = lv_fma(W.nA3[C1_A + (i)], lv2_y(b), W.g[3]);                                    \
+            if (LA) c3 = lv_fma(W.nA3[C1_A + (i)], lv2_y(b), c3);                                            \
         }
 #define XC_L_ROW(i)                                                                                          \
         {                                                                                                    \
-            const LV<T> b = row_impulse<3, i, K_NORMAL, 0>(G, W, (T)0);                                      \
-            g01 = lv2_make(lv2_x(g01), lv_fma(W.nA1[C1_L + i], b, lv2_y(g01)));                              \
-            if (PAD) W.g[2] = lv_fma(W.nA2[C2_L + i], b, W.g[2]);                                            \
-            W.g[3] = lv_fma(W.nA3[C1_L + i], b, W.g[3]);                                                     \
+            const LV<T> nl = lv_max0(c3);                                                                    \
+            const LV<T> dl = lv_sub(nl, W.lam[3]);                                                           \
+            lv_commit<i>(G, W.lam[3], nl);                                                                   \
+            const LV<T> b = lv_bcast<i>(dl);                                                                 \
+            c01 = lv2_make(lv2_x(c01), lv_fma(AL1[i], b, lv2_y(c01)));                                       \
+            if (PAD) c2 = lv_fma(W.nA2[C2_L + i], b, c2);                                                    \
+            c3 = lv_fma(W.nA3[C1_L + i], b, c3);                                                             \
         }
 #define XC_F_ROW(p, a)                                                                                       \
         {                                                                                                    \
-            const LV<T> b = row_impulse<2, 3 * p + a, (a == 0 ? K_NORMAL : K_FRICTION), 3 * p>(G, W, mu_p);   \
-            g01 = lv2_fma(nAF01[3 * p + a], lv2_make(b, b), g01);                                            \
-            W.g[2] = lv_fma(W.nA2[C2_F + 3 * p + a], b, W.g[2]);                                             \
-            if (LA) W.g[3] = lv_fma(W.nA3[C1_F + 3 * p + a], b, W.g[3]);                                     \
+            LV<T> nl;                                                                                        \
+            if ((a) == 0) nl = lv_max0(c2);                                                                  \
+            else {                                                                                           \
+                const LV<T> flim = lv_mul(lv_bcast<3 * p>(W.lam[2]), mu_pv);                                 \
+                nl = lv_med3(c2, lv_neg(flim), flim);                                                        \
+            }                                                                                                \
+            const LV<T> dl = lv_sub(nl, W.lam[2]);                                                           \
+            lv_commit<3 * p + a>(G, W.lam[2], nl);                                                           \
+            const LV<T> b = lv_bcast<3 * p + a>(dl);                                                         \
+            c01 = lv2_fma(AF01[3 * p + a], lv2_make(b, b), c01);                                             \
+            c2 = lv_fma(W.nA2[C2_F + 3 * p + a], b, c2);                                                     \
+            if (LA) c3 = lv_fma(W.nA3[C1_F + 3 * p + a], b, c3);                                             \
         }
 #define XC_F_PAD(p) if (padw[p]) { XC_F_ROW(p, 0) XC_F_ROW(p, 1) XC_F_ROW(p, 2) }
         XC_PAIR(0) XC_PAIR(1) XC_PAIR(2) XC_PAIR(3) XC_PAIR(4) XC_PAIR(5) XC_PAIR(6) XC_PAIR(7) XC_PAIR(8)

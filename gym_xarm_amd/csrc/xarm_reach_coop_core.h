@@ -273,9 +273,23 @@ template <typename T> XARM_HD void substep(const Grp &G, const BodyLane<T> &C, E
         invl.v[i_] = sg != (T)0 ? inv : (T)0;
         sgl.v[i_] = sg;
     }
-    LV2<T> g01 = xc::lv2_make(gm, gl), lam01 = xc::lv2_make(lv_fill((T)0), lv_fill((T)0)), invd01 = xc::lv2_make(invm, invl), nA01[ND];
-#pragma unroll
-    for (int r = 0; r < ND; r++) nA01[r] = xc::lv2_make(xc::lv_neg(Mi[r]), xc::lv_neg(xc::lv_mul(sgl, Mi[r])));
+    // the sweep carries c = lam + g / d per row (xarm_coop_core.h sweep_all: four dependent instructions per row step
+    // instead of five); the columns are scaled by the receiving row's 1 / d, a row's own entry is zero.  Motor r and
+    // limit r push the same joint but are different rows of lane r: one column pair per kind.
+    const LV2<T> invd01 = xc::lv2_make(invm, invl), zero2 = xc::lv2_make(lv_fill((T)0), lv_fill((T)0));
+    LV2<T> lam01 = zero2, c01 = xc::lv2_mul(xc::lv2_make(gm, gl), invd01), AM[ND], AL[ND];
+#define XRC_COL(r)                                                                                           \
+    {                                                                                                        \
+        const LV2<T> col = xc::lv2_mul(xc::lv2_make(xc::lv_neg(Mi[r]), xc::lv_neg(xc::lv_mul(sgl, Mi[r]))), invd01); \
+        LV<T> cx = xc::lv2_x(col), cy = xc::lv2_y(col);                                                      \
+        AM[r] = col; AL[r] = col;                                                                            \
+        lv_commit<r>(G, cx, lv_fill((T)0));                                                                  \
+        lv_commit<r>(G, cy, lv_fill((T)0));                                                                  \
+        AM[r] = xc::lv2_make(cx, xc::lv2_y(col));                                                            \
+        AL[r] = xc::lv2_make(xc::lv2_x(col), cy);                                                            \
+    }
+    XRC_COL(0) XRC_COL(1) XRC_COL(2) XRC_COL(3) XRC_COL(4) XRC_COL(5) XRC_COL(6) XRC_COL(7) XRC_COL(8) XRC_COL(9) XRC_COL(10) XRC_COL(11) XRC_COL(12)
+#undef XRC_COL
     bool lim_w[ND];   // limit row r is inside its window for some environment of the wavefront
 #define XRC_LIMW(r) lim_w[r] = XARM_ANY_X(lv_get<r>(sgl) != (T)0);
     XRC_LIMW(0) XRC_LIMW(1) XRC_LIMW(2) XRC_LIMW(3) XRC_LIMW(4) XRC_LIMW(5) XRC_LIMW(6) XRC_LIMW(7) XRC_LIMW(8) XRC_LIMW(9) XRC_LIMW(10) XRC_LIMW(11) XRC_LIMW(12)
@@ -286,24 +300,24 @@ template <typename T> XARM_HD void substep(const Grp &G, const BodyLane<T> &C, E
 #define XRC_MOTOR(r)                                                                                         \
         {                                                                                                    \
             const LV<T> lam = xc::lv2_x(lam01);                                                              \
-            const LV<T> nl = xc::lv_med3(xc::lv_fma(xc::lv2_x(g01), xc::lv2_x(invd01), lam), mlo, mhi);      \
+            const LV<T> nl = xc::lv_med3(xc::lv2_x(c01), mlo, mhi);                                          \
             const LV<T> dl = xc::lv_sub(nl, lam);                                                            \
             LV<T> nlam = lam;                                                                                \
             lv_commit<r>(G, nlam, nl);                                                                       \
             lam01 = xc::lv2_make(nlam, xc::lv2_y(lam01));                                                    \
             const LV<T> b = lv_bcast<r>(dl);                                                                 \
-            g01 = xc::lv2_fma(nA01[r], xc::lv2_make(b, b), g01);                                             \
+            c01 = xc::lv2_fma(AM[r], xc::lv2_make(b, b), c01);                                               \
         }
 #define XRC_LIMIT(r)                                                                                         \
         if (lim_w[r]) {                                                                                      \
             const LV<T> lam = xc::lv2_y(lam01);                                                              \
-            const LV<T> nl = xc::lv_max0(xc::lv_fma(xc::lv2_y(g01), xc::lv2_y(invd01), lam));                \
+            const LV<T> nl = xc::lv_max0(xc::lv2_y(c01));                                                    \
             const LV<T> dl = xc::lv_mul(xc::lv_sub(nl, lam), sgl);   /* impulse on the joint: sg * d lambda */ \
             LV<T> nlam = lam;                                                                                \
             lv_commit<r>(G, nlam, nl);                                                                       \
             lam01 = xc::lv2_make(xc::lv2_x(lam01), nlam);                                                    \
             const LV<T> b = lv_bcast<r>(dl);                                                                 \
-            g01 = xc::lv2_fma(nA01[r], xc::lv2_make(b, b), g01);                                             \
+            c01 = xc::lv2_fma(AL[r], xc::lv2_make(b, b), c01);                                               \
         }
         XRC_MOTOR(0) XRC_MOTOR(1) XRC_MOTOR(2) XRC_MOTOR(3) XRC_MOTOR(4) XRC_MOTOR(5) XRC_MOTOR(6) XRC_MOTOR(7) XRC_MOTOR(8) XRC_MOTOR(9)
         XRC_MOTOR(10) XRC_MOTOR(11) XRC_MOTOR(12)

@@ -507,6 +507,12 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
 #undef XC_COLL
     }
     const LV<T> mu_tv = lv_fill_vgpr(mu_t), mu_pv = lv_fill(mu_p);
+    // which arm-limit rows are live somewhere in the wavefront (usually one joint near one limit): the others are
+    // exact no-ops and are skipped, the launch lasts as long as its slowest wavefront
+    bool law[NLA];
+#define XC_LAW(i) law[i] = LA && XARM_ANY_X(lv_get<i>(W.invd[3]) != (T)0);
+    XC_LAW(0) XC_LAW(1) XC_LAW(2) XC_LAW(3) XC_LAW(4) XC_LAW(5) XC_LAW(6)
+#undef XC_LAW
 #pragma unroll 1
     for (int it = 0; it < XC_SWEEP_ITERS; it++) {
         LV<T> lim = lv_fill((T)0);
@@ -529,7 +535,7 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
             if (LA) c3 = lv_fma(W.nA3[C1_A + (i)], lv2_y(b), c3);                                            \
         }
 #define XC_L_ROW(i)                                                                                          \
-        {                                                                                                    \
+        if (law[i]) {                                                                                        \
             const LV<T> nl = lv_max0(c3);                                                                    \
             const LV<T> dl = lv_sub(nl, W.lam[3]);                                                           \
             lv_commit<i>(G, W.lam[3], nl);                                                                   \

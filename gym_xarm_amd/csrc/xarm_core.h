@@ -920,6 +920,11 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
     for (int i = 0; i < 7; i++) la_lane = la_lane || la_sg[i] != (T)0;
     const bool la_wave = XARM_ANY(la_lane);
+    // ... and which of the seven: at 65 536 envs a handful always have ONE joint near a limit, and the launch lasts as
+    // long as its slowest wavefront - that wavefront now sweeps the one row, not all seven
+    bool la_row[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) la_row[i] = la_wave && XARM_ANY(la_sg[i] != (T)0);
     // packed working set of the sweep: joint velocities as 4 pairs + dq[8], full columns of Minv as pairs
     Pk<T> dqp[4], MC[9][4];
     T dq8 = dq[8], ML[9];
@@ -982,7 +987,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         // (L) joint limits: arm (one side at most), then fingers (lower, upper)
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            if (!la_wave) continue;   // one wave-uniform test for all seven rows (decided once per substep)
+            if (!la_row[i]) continue;   // wave-uniform, decided once per substep
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;

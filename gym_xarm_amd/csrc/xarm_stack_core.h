@@ -512,6 +512,11 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
     for (int i = 0; i < 7; i++) la_lane = la_lane || la_sg[i] != (T)0;
     const bool la_wave = XARM_ANY(la_lane);
+    // ... and which of the seven: at 65 536 envs a handful always have ONE joint near a limit, and the launch lasts as
+    // long as its slowest wavefront - that wavefront now sweeps the one row, not all seven
+    bool la_row[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) la_row[i] = la_wave && XARM_ANY(la_sg[i] != (T)0);
     // packed working set of the sweep (as PickAndPlace): joint velocities as 4 pairs + dq[8], full Minv columns as pairs
     xk::Pk<T> dqp[4], MC[9][4];
     T dq8 = dq[8], ML[9];
@@ -578,7 +583,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
         // (L) joint limits
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            if (!la_wave) continue;   // one wave-uniform test for all seven rows (decided once per substep)
+            if (!la_row[i]) continue;   // wave-uniform, decided once per substep
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;

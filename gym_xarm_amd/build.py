@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libxarm_hip.so")
-SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h",
+SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h",
            "xarm_stack_core.h", "xarm_coop_core.h", "xarm_reach_coop_core.h"]
 # -fno-slp-vectorize: LLVM's SLP pass pairs the scalar fp32 ops of the unrolled solver into v_pk_* instructions,
 # which need even-aligned register pairs; in this 400-live-value kernel that costs ~30 % extra v_mov and pushes

@@ -22,6 +22,7 @@
 #include "xarm_core.h"
 #include "xarm_reach_core.h"
 #include "xarm_handover_core.h"
+#include "xarm_handover2_core.h"
 #include "xarm_stack_core.h"
 #include "xarm_coop_core.h"
 #include "xarm_reach_coop_core.h"
@@ -595,6 +596,147 @@ __global__ void k_ho_compute_reward(const float *__restrict__ ag, const float *_
     out[i] = sqrtf(dx * dx + dy * dy + dz * dz) > (float)xm::HO_DISTANCE_THRESHOLD ? -1.f : 0.f;
 }
 
+// --------------------------------------------------------------------- XarmHandover-v0, num_obj = 2 (two lanes per env)
+// the reference's test.py configuration (test.py:9-15); core xarm_handover2_core.h.  411 LDS floats per lane = 105 KB per
+// wavefront: one wavefront per CU.
+__device__ __forceinline__ void h2_load(const KParams &P, int64_t e, int arm, xh2::Lane<float> &L) {
+    const float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { L.q[i] = S[(xh2::G_Q + 9 * arm + i) * n]; L.qd[i] = S[(xh2::G_QD + 9 * arm + i) * n]; }
+    L.ft = S[(xh2::G_FT + arm) * n];
+#pragma unroll
+    for (int o = 0; o < xh2::NOBJ; o++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            L.bp[o][k] = S[(xh2::G_BP + 3 * o + k) * n]; L.bv[o][k] = S[(xh2::G_BV + 3 * o + k) * n];
+            L.bw[o][k] = S[(xh2::G_BW + 3 * o + k) * n]; L.goal[o][k] = S[(xh2::G_GOAL + 3 * o + k) * n];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) L.bq[o][k] = S[(xh2::G_BQ + 4 * o + k) * n];
+#pragma unroll
+        for (int k = 0; k < 8; k++) L.lam_t[o][k] = S[(xh2::G_LT + 8 * o + k) * n];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) L.lam_p[k] = S[(xh2::G_LP + 4 * arm + k) * n];
+    L.touch = S[(xh2::G_TOUCH + arm) * n]; L.mug = S[(xh2::G_MUG + arm) * n];
+    L.steps = S[xh2::G_STEPS * n]; L.episode = S[xh2::G_EPISODE * n];
+}
+__device__ __forceinline__ void h2_store(const KParams &P, int64_t e, int arm, const xh2::Lane<float> &L) {
+    float *S = P.state + e;
+    const int64_t n = P.stride;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { S[(xh2::G_Q + 9 * arm + i) * n] = L.q[i]; S[(xh2::G_QD + 9 * arm + i) * n] = L.qd[i]; }
+    S[(xh2::G_FT + arm) * n] = L.ft;
+#pragma unroll
+    for (int k = 0; k < 4; k++) S[(xh2::G_LP + 4 * arm + k) * n] = L.lam_p[k];
+    S[(xh2::G_TOUCH + arm) * n] = L.touch; S[(xh2::G_MUG + arm) * n] = L.mug;
+    if (arm == 0) { // shared fields are bit-identical in both lanes
+#pragma unroll
+        for (int o = 0; o < xh2::NOBJ; o++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                S[(xh2::G_BP + 3 * o + k) * n] = L.bp[o][k]; S[(xh2::G_BV + 3 * o + k) * n] = L.bv[o][k];
+                S[(xh2::G_BW + 3 * o + k) * n] = L.bw[o][k]; S[(xh2::G_GOAL + 3 * o + k) * n] = L.goal[o][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) S[(xh2::G_BQ + 4 * o + k) * n] = L.bq[o][k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) S[(xh2::G_LT + 8 * o + k) * n] = L.lam_t[o][k];
+        }
+        S[xh2::G_STEPS * n] = L.steps; S[xh2::G_EPISODE * n] = L.episode;
+    }
+}
+// observation (:314-329): stick pos 6, quat 8, v 6, w 6, then per arm grip pos 3, hand vel 3, finger q, qd
+__device__ __forceinline__ void h2_write_obs(const xh2::Lane<float> &L, int64_t e, int arm, float *obs_out, float *ag_out, float *dg_out) {
+    float o8[8];
+    xh2::arm_obs(L, arm, o8);
+    float *o = obs_out + e * xh2::OBS_DIM;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[26 + 8 * arm + k] = o8[k];
+    if (arm == 0) {
+#pragma unroll
+        for (int ob = 0; ob < xh2::NOBJ; ob++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                o[3 * ob + k] = L.bp[ob][k]; o[14 + 3 * ob + k] = L.bv[ob][k]; o[20 + 3 * ob + k] = L.bw[ob][k];
+                if (ag_out) { ag_out[e * 6 + 3 * ob + k] = L.bp[ob][k]; dg_out[e * 6 + 3 * ob + k] = L.goal[ob][k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[6 + 4 * ob + k] = L.bq[ob][k];
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_ho2_init(KParams P) {
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e = t >> 1;
+    const int arm = (int)(t & 1);
+    if (e >= P.num_envs) return;
+    xh2::Lane<float> L;
+    xh2::lane_init<float>(P.hcfg, e, L);
+    h2_store(P, e, arm, L);
+}
+__global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                 int *__restrict__ done_list, int *__restrict__ done_count,
+                                                 int *__restrict__ stale_count) {
+    __shared__ float smem[xh2::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int arm = (int)(t & 1);
+    if (t == 0 && stale_count) *stale_count = 0;
+    if (e_in >= P.num_envs) return;
+    DevLds lds{smem + threadIdx.x};
+    xh2::Lane<float> L;
+    h2_load(P, e_in, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float reward;
+    bool done, success;
+    xh2::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg());
+    const int64_t e = late_index(e_in);
+    h2_store(P, e, arm, L);
+    h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+    if (done && P.auto_reset && term_obs) h2_write_obs(L, e, arm, term_obs, nullptr, nullptr);
+    if (arm == 0) {
+        rew_out[e] = reward;
+        done_out[e] = done ? 1 : 0;
+        succ_out[e] = success ? 1 : 0;
+        if (done && P.auto_reset) {
+            const int pos = atomicAdd(done_count, 1);
+            done_list[pos] = (int)e;
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_ho2_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                  float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+    __shared__ float smem[xh2::LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
+    const int arm = (int)(t & 1);
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (i >= n) return;
+    const int64_t e_in = list ? (int64_t)list[i] : i;
+    DevLds lds{smem + threadIdx.x};
+    xh2::Lane<float> L;
+    h2_load(P, e_in, arm, L);
+    xh2::lane_reset<float, DevLds, DppXchg>(P.hcfg, e_in, L, arm, lds, DppXchg());
+    const int64_t e = late_index(e_in);
+    h2_store(P, e, arm, L);
+    if (obs_out) h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+}
+// xarm_handover.py:177-183 over n rows of 6: -sum_i [|ag_i - g_i| > thr]
+__global__ void k_ho2_compute_reward(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.f;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const float dx = ag[i * 6 + 3 * o] - g[i * 6 + 3 * o], dy = ag[i * 6 + 3 * o + 1] - g[i * 6 + 3 * o + 1], dz = ag[i * 6 + 3 * o + 2] - g[i * 6 + 3 * o + 2];
+        r += sqrtf(dx * dx + dy * dy + dz * dz) > (float)xm::HO_DISTANCE_THRESHOLD ? 1.f : 0.f;
+    }
+    out[i] = -r;
+}
+
 // --------------------------------------------------------------------- XarmPDStackTower-v0 (two lanes per env)
 // 603 LDS floats per lane = 151 KB per wavefront: one wavefront per CU, which is this scene's BASELINE size
 // (8192 envs per GPU = 256 wavefronts)
@@ -778,7 +920,8 @@ static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
 
 static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
                             hipStream_t st) {
-    if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    if (h->cfg.num_obj == 2) k_ho2_reset<<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    else if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
     else k_ho_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
 }
 
@@ -838,7 +981,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (cfg->env_kind != XARM_ENV_PICK_AND_PLACE && !reach && !handover && !stack) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: unsupported env_kind");
     if (stack && cfg->num_obj != 3) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower has num_obj == 3 (xarm_stack_tower.py:19)");
     if (stack && cfg->reward_type > 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower reward_type is 0 (sparse) or 1 (-d)");
-    if (!reach && !stack && cfg->num_obj != 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: this build supports num_obj == 1");
+    if (handover && cfg->num_obj != 1 && cfg->num_obj != 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover supports num_obj 1 or 2");
+    if (handover && cfg->num_obj == 2 && (cfg->reward_type != 0 || cfg->use_stand))
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover with num_obj == 2 takes the sparse reward and no stand (the reference's dense branch raises a broadcast error there, xarm_handover.py:187-188)");
+    if (!reach && !stack && !handover && cfg->num_obj != 1)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmPickAndPlace supports num_obj == 1 (with more the reference's own step raises, xarm_pick_and_place.py:289-291)");
     if (handover && cfg->reward_type != 0 && cfg->reward_type != XARM_REWARD_DENSE)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover reward_type is sparse (hard-wired in the reference, xarm_handover.py:40) or dense (:184-199)");
     if (cfg->use_stand && !handover) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: use_stand belongs to XarmHandover (xarm_handover.py:391-392)");
@@ -882,7 +1029,8 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         const char *ev = getenv("XARM_STEP_COOP_LIMIT");
         if (ev && *ev && (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH)) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
-    h->kp.state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
+    const bool handover2 = handover && cfg->num_obj == 2;
+    h->kp.state_dim = reach ? xr::STATE_DIM : (handover2 ? xh2::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM)));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
     h->kp.hcfg.same_side_rate = cfg->same_side_rate;
@@ -905,6 +1053,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     hipMemset(h->done_count, 0, sizeof(int) * 2);
     hipMemset(h->mask_count, 0, sizeof(int));
     if (reach) k_reach_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
+    else if (handover2) k_ho2_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
     else if (handover) k_ho_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
     else if (stack) k_st_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
     else k_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
@@ -936,10 +1085,11 @@ int xarm_dims(const xarm_handle *h, xarm_dims_t *out) {
     if (!out) return XARM_E_INVALID;
     const bool reach = h && h->cfg.env_kind == XARM_ENV_REACH, handover = h && h->cfg.env_kind == XARM_ENV_HANDOVER;
     const bool stack = h && h->cfg.env_kind == XARM_ENV_STACK_TOWER;
-    out->obs_dim = reach ? xr::OBS_DIM : (handover ? xh::OBS_DIM : (stack ? xs::OBS_DIM : xk::OBS_DIM));
-    out->goal_dim = stack ? xs::GOAL_DIM : xk::GOAL_DIM;
+    const bool handover2 = handover && h->cfg.num_obj == 2;
+    out->obs_dim = reach ? xr::OBS_DIM : (handover2 ? xh2::OBS_DIM : (handover ? xh::OBS_DIM : (stack ? xs::OBS_DIM : xk::OBS_DIM)));
+    out->goal_dim = stack ? xs::GOAL_DIM : (handover2 ? xh2::GOAL_DIM : xk::GOAL_DIM);
     out->act_dim = handover ? xh::ACT_DIM : (stack ? xs::ACT_DIM : xk::ACT_DIM);
-    out->state_dim = reach ? xr::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM));
+    out->state_dim = reach ? xr::STATE_DIM : (handover2 ? xh2::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM)));
     out->max_episode_steps = reach ? xmr::MAX_EPISODE_STEPS : (handover ? xm::HO_MAX_EPISODE_STEPS : (stack ? xm::ST_MAX_EPISODE_STEPS : xm::PNP_MAX_EPISODE_STEPS));
     out->n_substeps = reach ? xmr::N_SUBSTEPS : (handover ? xm::HO_N_TICKS : (stack ? xm::ST_N_SUBSTEPS : xm::PNP_N_SUBSTEPS));
     return XARM_OK;
@@ -992,6 +1142,9 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (stack)
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                        terminal_obs_dev, h->done_list, cnt, stale);
+    else if (handover && h->cfg.num_obj == 2)
+        k_ho2_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                        terminal_obs_dev, h->done_list, cnt, stale);
     else if (handover && h->kp.hcfg.use_stand)
         k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
                                                                            success_dev, terminal_obs_dev, h->done_list, cnt, stale);
@@ -1037,7 +1190,8 @@ int xarm_compute_reward(xarm_handle *h, const float *ag_dev, const float *g_dev,
         if (h->cfg.reward_type == XARM_REWARD_DENSE)
             return fail(h, XARM_E_INVALID, "%s", "xarm_compute_reward: reward_type 'dense' depends on the grasp flags and gripper positions and cannot be relabelled");
         if (n == 0) return XARM_OK;
-        k_ho_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
+        if (h->cfg.num_obj == 2) k_ho2_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
+        else k_ho_compute_reward<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ag_dev, g_dev, n, out_dev);
         HIPCHK(h, hipGetLastError());
         return XARM_OK;
     }
@@ -1077,7 +1231,7 @@ int xarm_set_state(xarm_handle *h, const float *state_dev, void *stream) {
 int xarm_episode_steps(xarm_handle *h, int32_t *steps_dev, void *stream) {
     if (!h || !steps_dev) return XARM_E_INVALID;
     DEVGUARD(h);
-    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (int)xh::H_STEPS :
+    const int field = h->cfg.env_kind == XARM_ENV_REACH ? (int)xr::R_STEPS : (h->cfg.env_kind == XARM_ENV_HANDOVER ? (h->cfg.num_obj == 2 ? (int)xh2::G_STEPS : (int)xh::H_STEPS) :
                       (h->cfg.env_kind == XARM_ENV_STACK_TOWER ? (int)xs::K_STEPS : (int)xk::S_STEPS));
     k_episode_steps<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(h->kp, field, steps_dev);
     HIPCHK(h, hipGetLastError());

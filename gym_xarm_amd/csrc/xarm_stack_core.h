@@ -79,8 +79,10 @@ template <typename T, typename Lds> XARM_HD int clip_axis(Lds lds, int in, int n
     }
     return m;
 }
-template <typename T, typename Lds>
-XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[3], T h, T margin, V3<T> (&pts)[4], V3<T> &nrm, T (&dist)[4], Lds lds) {
+// box_box: general half extents hA / hB (the Handover sticks, xarm_handover2_core.h); CLIP = first of the 72 LDS columns
+// that hold the clipped polygon.  cube_cube below is the same code with hA = hB = (h, h, h).
+template <typename T, typename Lds, int CLIP>
+XARM_HD int box_box(V3<T> pA, const V3<T> (&A)[3], const T (&hA)[3], V3<T> pB, const V3<T> (&B)[3], const T (&hB)[3], T margin, V3<T> (&pts)[4], V3<T> &nrm, T (&dist)[4], Lds lds) {
     const V3<T> t = pB - pA;
     T tA[3], tB[3], C[3][3], Q[3][3];
 #pragma unroll
@@ -94,13 +96,13 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
     bool sep = false;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const T s = xk::xabs(tA[i]) - (h + h * Q[i][0] + h * Q[i][1] + h * Q[i][2]);
+        const T s = xk::xabs(tA[i]) - (hA[i] + hB[0] * Q[i][0] + hB[1] * Q[i][1] + hB[2] * Q[i][2]);
         sep = sep || s > margin;
         if (s > best) { best = s; code = i; }
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        const T s = xk::xabs(tB[j]) - (h + h * Q[0][j] + h * Q[1][j] + h * Q[2][j]);
+        const T s = xk::xabs(tB[j]) - (hB[j] + hA[0] * Q[0][j] + hA[1] * Q[1][j] + hA[2] * Q[2][j]);
         sep = sep || s > margin;
         if (s > best) { best = s; code = 3 + j; }
     }
@@ -117,7 +119,7 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
             const bool ok = !(l2 < (T)1e-6);
             const T l = xk::xsqrt(ok ? l2 : (T)1);
             const T expr = tA[i2] * C[i1][j] - tA[i1] * C[i2][j];
-            const T ra = h * Q[i2][j] + h * Q[i1][j], rb = h * Q[i][j2] + h * Q[i][j1];
+            const T ra = hA[i1] * Q[i2][j] + hA[i2] * Q[i1][j], rb = hB[j1] * Q[i][j2] + hB[j2] * Q[i][j1];
             const T s = (xk::xabs(expr) - (ra + rb)) / l;
             sep = sep || (ok && s > margin);
             if (ok && s > ebest) {
@@ -133,7 +135,7 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
         V3<T> pa = pA, pb = pB;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const V3<T> da = A[k] * ((dot(eaxis, A[k]) >= (T)0 ? (T)1 : (T)-1) * h), db = B[k] * ((dot(eaxis, B[k]) >= (T)0 ? (T)-1 : (T)1) * h);
+            const V3<T> da = A[k] * ((dot(eaxis, A[k]) >= (T)0 ? (T)1 : (T)-1) * hA[k]), db = B[k] * ((dot(eaxis, B[k]) >= (T)0 ? (T)-1 : (T)1) * hB[k]);
             pa = k != ei ? pa + da : pa;
             pb = k != ej ? pb + db : pb;
         }
@@ -167,20 +169,27 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
     const V3<T> Ijj = sel3v(jj, Ix[0], Ix[1], Ix[2]), Ij1 = sel3v(jj, Ix[1], Ix[2], Ix[0]), Ij2 = sel3v(jj, Ix[2], Ix[0], Ix[1]);
     const V3<T> Rr1 = sel3v(ri, Rx[1], Rx[2], Rx[0]), Rr2 = sel3v(ri, Rx[2], Rx[0], Rx[1]);
     const T sj = dot(Ijj, dR) > (T)0 ? (T)-1 : (T)1;
-    constexpr int P0 = LDS_CLIP, P1 = LDS_CLIP + 24, KP = LDS_CLIP + 48;
+    // half extents of the reference / incident box along the selected axes
+    const T hRi = refA ? sel3(ri, hA[0], hA[1], hA[2]) : sel3(ri, hB[0], hB[1], hB[2]);
+    const T hR1 = refA ? sel3(ri, hA[1], hA[2], hA[0]) : sel3(ri, hB[1], hB[2], hB[0]);
+    const T hR2 = refA ? sel3(ri, hA[2], hA[0], hA[1]) : sel3(ri, hB[2], hB[0], hB[1]);
+    const T hIj = refA ? sel3(jj, hB[0], hB[1], hB[2]) : sel3(jj, hA[0], hA[1], hA[2]);
+    const T hI1 = refA ? sel3(jj, hB[1], hB[2], hB[0]) : sel3(jj, hA[1], hA[2], hA[0]);
+    const T hI2 = refA ? sel3(jj, hB[2], hB[0], hB[1]) : sel3(jj, hA[2], hA[0], hA[1]);
+    constexpr int P0 = CLIP, P1 = CLIP + 24, KP = CLIP + 48;
     int n = 4;
 #pragma unroll
     for (int v = 0; v < 4; v++) {
         const T su = (v == 0 || v == 3) ? (T)1 : (T)-1, sv = v < 2 ? (T)1 : (T)-1;
-        const V3<T> w = pI + Ijj * (sj * h) + Ij1 * (su * h) + Ij2 * (sv * h) - pR;
+        const V3<T> w = pI + Ijj * (sj * hIj) + Ij1 * (su * hI1) + Ij2 * (sv * hI2) - pR;
         lds[P0 + 3 * v] = dot(w, Rr1);
         lds[P0 + 3 * v + 1] = dot(w, Rr2);
-        lds[P0 + 3 * v + 2] = dot(w, dR) - h;
+        lds[P0 + 3 * v + 2] = dot(w, dR) - hRi;
     }
-    n = clip_axis<T, Lds>(lds, P0, n, P1, 0, (T)1, h);
-    n = clip_axis<T, Lds>(lds, P1, n, P0, 0, (T)-1, h);
-    n = clip_axis<T, Lds>(lds, P0, n, P1, 1, (T)1, h);
-    n = clip_axis<T, Lds>(lds, P1, n, P0, 1, (T)-1, h);
+    n = clip_axis<T, Lds>(lds, P0, n, P1, 0, (T)1, hR1);
+    n = clip_axis<T, Lds>(lds, P1, n, P0, 0, (T)-1, hR1);
+    n = clip_axis<T, Lds>(lds, P0, n, P1, 1, (T)1, hR2);
+    n = clip_axis<T, Lds>(lds, P1, n, P0, 1, (T)-1, hR2);
     int nk = 0;
     for (int i = 0; i < n; i++)
         if (lds[P0 + 3 * i + 2] < margin) {
@@ -217,12 +226,17 @@ XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[
         const int si = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
         if (q < ns) {
             const T vx = lds[KP + 3 * si], vy = lds[KP + 3 * si + 1], vz = lds[KP + 3 * si + 2];
-            pts[q] = pR + Rr1 * vx + Rr2 * vy + dR * (vz + h);
+            pts[q] = pR + Rr1 * vx + Rr2 * vy + dR * (vz + hRi);
             dist[q] = vz;
         }
     }
     nrm = refA ? dR * (T)-1 : dR;
     return ns;
+}
+template <typename T, typename Lds>
+XARM_HD int cube_cube(V3<T> pA, const V3<T> (&A)[3], V3<T> pB, const V3<T> (&B)[3], T h, T margin, V3<T> (&pts)[4], V3<T> &nrm, T (&dist)[4], Lds lds) {
+    const T hh[3] = {h, h, h};
+    return box_box<T, Lds, LDS_CLIP>(pA, A, hh, pB, B, hh, margin, pts, nrm, dist, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Single-environment view with the reference's call surface (/root/reference/gym_xarm/envs/xarm_handover.py:19):
-`XarmHandover(config)` with config keys GUI / num_obj / same_side_rate / goal_shape / use_stand (test.py:9-15),
+`XarmHandover(config)` with config keys GUI / num_obj (1 or 2) / same_side_rate / goal_shape / use_stand (test.py:9-15),
 numpy in/out.  A 1-env XarmHandoverVecEnv (HIP kernels, two lanes = two arms) sits behind it."""
 import numpy as np
 import torch
@@ -35,7 +35,7 @@ class XarmHandover:
     def compute_reward(self, achieved_goal, goal, info=None):
         ag = np.asarray(achieved_goal, dtype=np.float32)
         out = self._vec.compute_reward(ag, np.asarray(goal, dtype=np.float32)).cpu().numpy()
-        return out if ag.ndim > 1 else float(out)
+        return float(out.reshape(-1)[0]) if out.size == 1 else out      # `if len(rew) == 1: return rew[0]` (:180-183)
 
     def seed(self, seed=None):
         return self._vec.seed(seed)

@@ -331,27 +331,36 @@ HANDOVER_CONFIG_DEFAULTS = {"GUI": False, "num_obj": 1, "same_side_rate": 0.5, "
 
 class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
     """E independent XarmHandover-v0 environments (/root/reference/gym_xarm/envs/xarm_handover.py:19): two xArm7 +
-    Panda-gripper arms, one stick, two tables with a gap; obs 29 (:325-329), action 8 (:118), sparse reward
-    -[d > 0.05] (:177-183) or the staged dense reward (:184-199), done = success or 100 steps (:138 + registry),
-    config['use_stand'] (:391-392): a static stand under the goal.  num_obj = 1."""
+    Panda-gripper arms, config['num_obj'] = 1 or 2 sticks, two tables with a gap; obs 13 N + 16 = 29 / 42 (:325-329),
+    achieved / desired goal 3 N, action 8 (:118), sparse reward -sum_i [d_i > 0.05] (:177-183) or, for one stick, the
+    staged dense reward (:184-199); done = success (every stick within 0.05 of its goal, :395-402) or 100 steps (:138 +
+    registry); config['use_stand'] (:391-392, one stick): a static stand under the goal.  num_obj = 2 is the reference's
+    test.py configuration (test.py:9-15): the second stick / goal are rejection-sampled (:357-360, :375-379)."""
 
     ENV_KIND = _native.ENV_HANDOVER
-    AG_SLICE = slice(0, 3)    # achieved_goal = object position (xarm_handover.py:325-336)
+    AG_SLICE = slice(0, 3)    # achieved_goal = object position(s), first in the observation (xarm_handover.py:325-336)
 
     def _check_config(self, config):
         cfg = dict(HANDOVER_CONFIG_DEFAULTS)
         cfg.update(config or {})
-        if cfg["num_obj"] != 1:
-            raise NotImplementedError("this build supports num_obj == 1")
+        if cfg["num_obj"] not in (1, 2):
+            raise NotImplementedError("XarmHandover supports num_obj 1 (BASELINE config 5) or 2 (the reference's test.py)")
         # the reference hard-wires reward_type = 'sparse' (xarm_handover.py:40); its staged 'dense' branch (:184-199) is
         # offered as an opt-in config key (the undefined `d` of its last stage = object-to-goal distance)
         cfg.setdefault("reward_type", "sparse")
         if cfg["reward_type"] not in ("sparse", "dense"):
             raise NotImplementedError("XarmHandover reward_type %r" % (cfg["reward_type"],))
+        if cfg["num_obj"] == 2 and cfg["reward_type"] == "dense":
+            # not runnable in the reference either: grip_pos_1 (3,) - achieved_goal (6,) is a NumPy broadcast error (:187)
+            raise NotImplementedError("XarmHandover reward_type 'dense' with num_obj == 2 raises in the reference itself "
+                                      "(xarm_handover.py:187-188: a (3,) grip position minus the (6,) achieved_goal)")
+        if cfg["num_obj"] == 2 and cfg["use_stand"]:
+            raise NotImplementedError("use_stand with num_obj == 2 is not built (test.py:9-15 runs without stands)")
+        self.AG_SLICE = slice(0, 3 * cfg["num_obj"])
         return cfg
 
     def _native_config(self):
-        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, 1,
+        return _native.XarmConfig(self.num_envs, self._env_id_offset, self._seed, self.ENV_KIND, int(self.config["num_obj"]),
                                   _native.REWARD_TYPES[self.config["reward_type"]],
                                   1 if self.config["goal_shape"] == "ground" else 0, 0.0, 0.0, int(self._auto_reset),
                                   self.device.index if self.device.index is not None else torch.cuda.current_device(),

@@ -72,7 +72,7 @@ typedef struct xarm_config {
     int64_t env_id_offset;  /* global id of env 0 of the shard; the RNG is keyed by global id */
     uint64_t seed;
     int32_t env_kind;       /* XARM_ENV_* */
-    int32_t num_obj;        /* config['num_obj']; this build supports 1 */
+    int32_t num_obj;        /* config['num_obj']: 1; XarmHandover also 2 (the reference's test.py:9-15: obs 42, goals 6); StackTower 3 */
     int32_t reward_type;    /* XARM_REWARD_* (config['reward_type']) */
     int32_t goal_shape;     /* XARM_GOAL_*   (config['goal_shape']) */
     float init_grasp_rate;  /* config['init_grasp_rate'] */
@@ -115,7 +115,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
               float *desired_goal_dev, float *reward_dev, uint8_t *done_dev, uint8_t *success_dev,
               float *terminal_obs_dev, void *stream);
 
-/* compute_reward(achieved_goal, goal, info) over n rows of 3 floats (HER relabelling) */
+/* compute_reward(achieved_goal, goal, info) over n rows of goal_dim floats (HER relabelling) */
 int xarm_compute_reward(xarm_handle *h, const float *achieved_goal_dev, const float *goal_dev, int64_t n,
                         float *out_dev, void *stream);
 

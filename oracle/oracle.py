@@ -74,10 +74,12 @@ class XoHoCfg(C.Structure):
                 ("finger_motor_force", _d), ("distance_threshold", _d), ("obj_half", _d * 3), ("eef2grip", _d * 3),
                 ("table_x_min", _d), ("table_x_max", _d), ("table_half_y", _d), ("ground_z", _d),
                 ("reset_ticks", _i), ("max_episode_steps", _i), ("reward_type", _i), ("use_stand", _i),
-                ("stand_half", _d * 3), ("stand_below_goal", _d)]
+                ("stand_half", _d * 3), ("stand_below_goal", _d),
+                ("spawn_min_dy", _d), ("goal_min_dy", _d), ("goal_min_obj_dist", _d), ("sample_max_tries", _i), ("_pad2", _i)]
 
 
 HO_STATE_DIM, HO_OBS_DIM, HO_ACT_DIM = 76, 29, 8
+HO2_STATE_DIM, HO2_OBS_DIM, HO2_GOAL_DIM = 100, 42, 6
 
 
 class XoStCfg(C.Structure):
@@ -181,6 +183,10 @@ def lib():
         L.xo_ho_reset.argtypes = [mp, hp, C.c_int64, dp, u8p, dp, dp, dp]
         L.xo_ho_step.argtypes = [mp, hp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
         L.xo_ho_compute_reward.argtypes = [hp, C.c_int64, dp, dp, dp]
+        L.xo_ho2_init.argtypes = [mp, hp, C.c_int64, dp]
+        L.xo_ho2_reset.argtypes = [mp, hp, C.c_int64, dp, u8p, dp, dp, dp]
+        L.xo_ho2_step.argtypes = [mp, hp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
+        L.xo_ho2_compute_reward.argtypes = [hp, C.c_int64, dp, dp, dp]
         sp = C.POINTER(XoStCfg)
         L.xo_st_init.argtypes = [mp, sp, C.c_int64, dp]
         L.xo_st_reset.argtypes = [mp, sp, C.c_int64, dp, u8p, dp, dp, dp]
@@ -314,10 +320,18 @@ class OracleReach:
 
 
 class OracleHandover:
-    """Batched CPU XarmHandover-v0 (xarm_handover.py, num_obj = 1, use_stand False), float64."""
+    """Batched CPU XarmHandover-v0 (xarm_handover.py), float64.  num_obj = 1 (BASELINE config 5) or 2 (the reference's
+    test.py configuration; sparse reward, no stand)."""
 
-    def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground", reward_type="sparse", use_stand=False):
+    def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground", reward_type="sparse", use_stand=False,
+                 num_obj=1):
         self.L = lib()
+        assert num_obj in (1, 2)
+        if num_obj == 2 and (reward_type != "sparse" or use_stand):
+            raise ValueError("num_obj = 2: sparse reward without stand only (the reference's dense branch raises, xarm_handover.py:187-188)")
+        self.num_obj = num_obj
+        self.state_dim, self.obs_dim, self.goal_dim = (HO_STATE_DIM, HO_OBS_DIM, 3) if num_obj == 1 else (HO2_STATE_DIM, HO2_OBS_DIM, HO2_GOAL_DIM)
+        self._fn = {k: getattr(self.L, ("xo_ho_" if num_obj == 1 else "xo_ho2_") + k) for k in ("init", "reset", "step", "compute_reward")}
         js = load_model_json()
         self.m = build_model(js)
         h = js["handover"]
@@ -341,39 +355,41 @@ class OracleHandover:
                      ("obj_half", 3), ("eef2grip", 3)):
             for i in range(n):
                 getattr(c, k)[i] = h[k][i]
+        for k in ("spawn_min_dy", "goal_min_dy", "goal_min_obj_dist", "sample_max_tries"):
+            setattr(c, k, h[k])
         self.cfg = c
         self.E = int(num_envs)
-        self.state = np.zeros((self.E, HO_STATE_DIM))
-        self.L.xo_ho_init(self.m, self.cfg, self.E, _p(self.state))
+        self.state = np.zeros((self.E, self.state_dim))
+        self._fn["init"](self.m, self.cfg, self.E, _p(self.state))
 
     def _bufs(self):
-        return np.zeros((self.E, HO_OBS_DIM)), np.zeros((self.E, 3)), np.zeros((self.E, 3))
+        return np.zeros((self.E, self.obs_dim)), np.zeros((self.E, self.goal_dim)), np.zeros((self.E, self.goal_dim))
 
     def reset(self, mask=None):
         obs, ag, dg = self._bufs()
         mk = None if mask is None else _u8(np.ascontiguousarray(mask, dtype=np.uint8))
-        self.L.xo_ho_reset(self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
+        self._fn["reset"](self.m, self.cfg, self.E, _p(self.state), mk, _p(obs), _p(ag), _p(dg))
         return obs, ag, dg
 
     def step(self, actions):
         actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.E, HO_ACT_DIM)
         obs, ag, dg = self._bufs()
         rew, done, succ = np.zeros(self.E), np.zeros(self.E, np.uint8), np.zeros(self.E, np.uint8)
-        self.L.xo_ho_step(self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg), _p(rew), _u8(done), _u8(succ))
+        self._fn["step"](self.m, self.cfg, self.E, _p(self.state), _p(actions), _p(obs), _p(ag), _p(dg), _p(rew), _u8(done), _u8(succ))
         return obs, ag, dg, rew, done, succ
 
     def compute_reward(self, ag, g):
-        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, 3)
-        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, 3)
+        ag = np.ascontiguousarray(ag, dtype=np.float64).reshape(-1, self.goal_dim)
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1, self.goal_dim)
         out = np.zeros(ag.shape[0])
-        self.L.xo_ho_compute_reward(self.cfg, ag.shape[0], _p(ag), _p(g), _p(out))
+        self._fn["compute_reward"](self.cfg, ag.shape[0], _p(ag), _p(g), _p(out))
         return out
 
     def get_state(self):
         return self.state.copy()
 
     def set_state(self, s):
-        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, HO_STATE_DIM)
+        self.state[...] = np.asarray(s, dtype=np.float64).reshape(self.E, self.state_dim)
 
 
 class OracleStackTower:

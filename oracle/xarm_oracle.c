@@ -1570,3 +1570,4 @@ int xo_ho_step(const xo_model *m, const xo_ho_cfg *c, int64_t E, double *state, 
 }
 
 #include "xarm_oracle_stack.inc.c"
+#include "xarm_oracle_handover2.inc.c"

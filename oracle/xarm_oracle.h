@@ -143,6 +143,9 @@ typedef struct {
     int32_t reward_type;        /* 0 sparse (hard-wired in the reference, :40), 1 the staged dense reward (:184-199) */
     int32_t use_stand;          /* config['use_stand'] (:391-392): a static box under the goal */
     double stand_half[3], stand_below_goal; /* my_stand.urdf box 0.07 x 0.06 x 0.01; centre = goal - (0,0,stand_below_goal) */
+    /* num_obj = 2 (xo_ho2_*): rejection sampling of the second stick / goal (:357-360, :375-379) */
+    double spawn_min_dy, goal_min_dy, goal_min_obj_dist;
+    int32_t sample_max_tries, _pad2;
 } xo_ho_cfg;
 int xo_ho_init(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state);
 int xo_ho_reset(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,
@@ -155,6 +158,18 @@ int xo_ho_step(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state
 double xo_ho_dense_reward(const double *grip1, const double *grip2, int if1, int if2, const double *ag, const double *g);
 /* sparse reward of xarm_handover.py:177-183 for N = 1 over n rows */
 int xo_ho_compute_reward(const xo_ho_cfg *cfg, int64_t n, const double *ag, const double *g, double *out);
+/* ---- XarmHandover-v0 with config['num_obj'] = 2 (test.py:9-15; xarm_oracle_handover2.inc.c) ---- */
+#define XO_HO2_STATE_DIM 100 /* q[2][9] qd[2][9] finger_target[2] obj_pos[2][3] obj_quat[2][4] obj_v[2][3] obj_w[2][3]
+                                goal[2][3] lam_table[2][8] lam_pad[2][4] touch[2] mu_grasp[2] num_steps episode */
+#define XO_HO2_OBS_DIM 42    /* 13 N + 16 (:325-329) */
+#define XO_HO2_GOAL_DIM 6
+int xo_ho2_init(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state);
+int xo_ho2_reset(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const uint8_t *mask, double *obs,
+                 double *ag, double *dg);
+int xo_ho2_step(const xo_model *m, const xo_ho_cfg *cfg, int64_t E, double *state, const double *actions, double *obs,
+                double *ag, double *dg, double *reward, uint8_t *done, uint8_t *success);
+/* sparse reward -sum_i [|ag_i - g_i| > thr] over n rows of 6 (:177-183) */
+int xo_ho2_compute_reward(const xo_ho_cfg *cfg, int64_t n, const double *ag, const double *g, double *out);
 /* ---- XarmPDStackTower-v0 (xarm_stack_tower.py), two xarm7_pd arms + three cubes ---- */
 #define XO_ST_STATE_DIM 136 /* q[2][9] qd[2][9] motor_target[2][9] cube_pos[3][3] cube_quat[3][4] cube_v[3][3]
                                cube_w[3][3] goal[3][3] lam_table[3][8] lam_pad[2][4] num_steps episode */

@@ -35,6 +35,7 @@ typedef struct {
     const xo_st_cfg *c;
     tree_t t[2];
     real imass, iinertia;
+    const real *Iinv_w;     /* NULL: isotropic bodies (cubes, 1 / iinertia); else [nobj][9] world inverse inertia tensors */
     srow_t rows[ST_MAXROWS];
     int nrows;
 } ssolver_t;
@@ -51,10 +52,16 @@ static void srow_finish(ssolver_t *s, srow_t *r) {
         aba_impulse_response(s->m, &s->t[r->arm], r->Ja, r->Ba);
         for (int k = 0; k < 9; k++) d += r->Ja[k] * r->Ba[k];
     }
-    if (r->bp >= 0)
-        for (int k = 0; k < 6; k++) { r->Bp[k] = r->Jp[k] * (k < 3 ? s->imass : s->iinertia); d += r->Jp[k] * r->Bp[k]; }
-    if (r->bn >= 0)
-        for (int k = 0; k < 6; k++) { r->Bn[k] = r->Jn[k] * (k < 3 ? s->imass : s->iinertia); d += r->Jn[k] * r->Bn[k]; }
+    if (r->bp >= 0) {
+        for (int k = 0; k < 6; k++) r->Bp[k] = r->Jp[k] * (k < 3 ? s->imass : s->iinertia);
+        if (s->Iinv_w) m3_vec(r->Bp + 3, s->Iinv_w + 9 * r->bp, r->Jp + 3);
+        for (int k = 0; k < 6; k++) d += r->Jp[k] * r->Bp[k];
+    }
+    if (r->bn >= 0) {
+        for (int k = 0; k < 6; k++) r->Bn[k] = r->Jn[k] * (k < 3 ? s->imass : s->iinertia);
+        if (s->Iinv_w) m3_vec(r->Bn + 3, s->Iinv_w + 9 * r->bn, r->Jn + 3);
+        for (int k = 0; k < 6; k++) d += r->Jn[k] * r->Bn[k];
+    }
     r->inv_d = 1.0 / (d + r->cfm);
 }
 /* three rows of one contact point; n points from the negative body to the positive one.
@@ -278,6 +285,7 @@ static void st_substep(const xo_model *m, const xo_st_cfg *c, real *st, real dt)
     static const int pair_a[ST_NPAIR] = {0, 0, 1}, pair_b[ST_NPAIR] = {1, 2, 2};
     ssolver_t s;
     s.m = m; s.c = c; s.nrows = 0;
+    s.Iinv_w = 0;
     s.imass = 1.0 / c->cube_mass;
     s.iinertia = 1.0 / (c->cube_mass * 2.0 / 3.0 * c->cube_half * c->cube_half);  /* m/12 (2a)^2 * 2 */
     for (int a = 0; a < 2; a++) {

@@ -47,7 +47,7 @@ class HostCore:
         d = os.path.join(ROOT, "tests", "hostbuild")
         so = os.path.join(d, "libxarm_host.so")
         srcs = [os.path.join(d, "xarm_host.cpp")] + [os.path.join(ROOT, "gym_xarm_amd", "csrc", f) for f in (
-            "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_stack_core.h",
+            "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h", "xarm_stack_core.h",
             "xarm_coop_core.h", "xarm_reach_coop_core.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
@@ -212,6 +212,38 @@ class HostCore:
         self.L.xh_ho_reset(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st), mk,
                            self._p(obs), self._p(ag), self._p(dg))
         return st, obs, ag, dg
+
+    # ---- Handover with num_obj = 2 (csrc/xarm_handover2_core.h)
+    def ho2_init(self, E, f32=1, seed=0, off=0, ssr=0.5, gs=1):
+        st = np.zeros((E, 100))
+        self.L.xh_ho2_init(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st))
+        return st
+
+    def ho2_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1):
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 42)), np.zeros((E, 6)), np.zeros((E, 6))
+        rew, done, succ = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self.L.xh_ho2_step(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st),
+                           self._p(a), self._p(obs), self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
+        return st, obs, ag, dg, rew, done, succ
+
+    def ho2_reset(self, state, mask=None, f32=1, seed=0, off=0, ssr=0.5, gs=1):
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        obs, ag, dg = np.zeros((E, 42)), np.zeros((E, 6)), np.zeros((E, 6))
+        mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xh_ho2_reset(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st), mk,
+                            self._p(obs), self._p(ag), self._p(dg))
+        return st, obs, ag, dg
+
+    def box_box(self, pA, RA, hA, pB, RB, hB, margin=0.005, f32=0):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pA, RA, hA, pB, RB, hB)]
+        pts, nrm, dist = np.zeros((4, 3)), np.zeros(3), np.zeros(4)
+        self.L.xh_box_box.restype = C.c_int
+        n = self.L.xh_box_box(C.c_int(f32), *[self._p(x) for x in a], C.c_double(margin), self._p(pts), self._p(nrm), self._p(dist))
+        return pts[:n].copy(), nrm, dist[:n].copy()
 
     def ik(self, q, target, f32=1):
         out = np.zeros(9)

@@ -7,7 +7,10 @@
 #define XARM_HOST_BUILD 1
 #include "../../gym_xarm_amd/csrc/xarm_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_reach_core.h"
+#include <atomic>
+#include <sched.h>
 #include "../../gym_xarm_amd/csrc/xarm_handover_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_handover2_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_stack_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_coop_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_reach_coop_core.h"
@@ -203,14 +206,30 @@ template <typename T> void reach_init(const xr::EnvCfg &c, int64_t E, double *st
 
 // ---- Handover: the two lanes of an environment run as two host threads, the lane-pair exchange is a slot + barrier
 namespace {
-struct PairShared { pthread_barrier_t bar; double slot[2]; };
+// two-party sense-reversing spin barrier: the lane pair exchanges thousands of values per tick, and a futex-based
+// pthread barrier made the emulation ~50x slower than the arithmetic it synchronises
+struct SpinBarrier {
+    std::atomic<int> count{0}, gen{0};
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == 2) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == g)
+                if (++spins > 4096) { sched_yield(); spins = 0; }
+        }
+    }
+};
+struct PairShared { SpinBarrier bar; double slot[2]; };
 struct PairXchg {
     PairShared *sh; int arm;
     template <typename T> T get(int src, T v) const {
         sh->slot[arm] = (double)v;
-        pthread_barrier_wait(&sh->bar);
+        sh->bar.wait();
         T r = (T)sh->slot[src];
-        pthread_barrier_wait(&sh->bar);
+        sh->bar.wait();
         return r;
     }
     template <typename T> T from0(T v) const { return get(0, v); }
@@ -257,7 +276,7 @@ template <typename T> void *ho_thread(void *p) {
         else xh::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
         T o8[8];
         xh::arm_obs(L, J.arm, o8);
-        pthread_barrier_wait(&J.sh->bar);   // both lanes finished computing before anyone overwrites the row
+        J.sh->bar.wait();   // both lanes finished computing before anyone overwrites the row
         hstore(L, J.arm, J.state + e * xh::STATE_DIM);
         double *o = J.obs + e * xh::OBS_DIM;
         for (int k = 0; k < 8; k++) o[13 + 8 * J.arm + k] = o8[k];
@@ -266,19 +285,17 @@ template <typename T> void *ho_thread(void *p) {
             for (int k = 0; k < 4; k++) o[3 + k] = L.st.bq[k];
             if (J.mode == 0) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
         }
-        pthread_barrier_wait(&J.sh->bar);
+        J.sh->bar.wait();
     }
     return 0;
 }
 template <typename T> void ho_run(int mode, const xh::EnvCfg &cfg, int64_t E, double *state, const double *act, const uint8_t *mask,
                                   double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
     PairShared sh;
-    pthread_barrier_init(&sh.bar, 0, 2);
     HoJob<T> j[2];
     pthread_t th[2];
     for (int a = 0; a < 2; a++) { j[a] = HoJob<T>{mode, cfg, E, state, act, mask, obs, ag, dg, rew, done, succ, &sh, a}; pthread_create(&th[a], 0, ho_thread<T>, &j[a]); }
     for (int a = 0; a < 2; a++) pthread_join(th[a], 0);
-    pthread_barrier_destroy(&sh.bar);
 }
 }
 
@@ -391,7 +408,7 @@ template <typename T> void *st_thread(void *p) {
         } else xs::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
         T o8[8];
         xs::arm_obs(L, J.arm, o8);
-        pthread_barrier_wait(&J.sh->bar);
+        J.sh->bar.wait();
         sstore(L, J.arm, J.state + e * xs::STATE_DIM);
         double *o = J.obs + e * xs::OBS_DIM;
         for (int k = 0; k < 8; k++) o[39 + 8 * J.arm + k] = o8[k];
@@ -405,19 +422,17 @@ template <typename T> void *st_thread(void *p) {
             }
             if (J.mode == 0) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
         }
-        pthread_barrier_wait(&J.sh->bar);
+        J.sh->bar.wait();
     }
     return 0;
 }
 template <typename T> void st_run(int mode, const xk::EnvCfg &cfg, int64_t E, double *state, const double *act, const uint8_t *mask,
                                   double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
     PairShared sh;
-    pthread_barrier_init(&sh.bar, 0, 2);
     StJob<T> j[2];
     pthread_t th[2];
     for (int a = 0; a < 2; a++) { j[a] = StJob<T>{mode, cfg, E, state, act, mask, obs, ag, dg, rew, done, succ, &sh, a}; pthread_create(&th[a], 0, st_thread<T>, &j[a]); }
     for (int a = 0; a < 2; a++) pthread_join(th[a], 0);
-    pthread_barrier_destroy(&sh.bar);
 }
 static xk::EnvCfg scfg(uint64_t seed, int64_t off, int rt) { xk::EnvCfg c; memset(&c, 0, sizeof c); c.seed = seed; c.env_id_offset = off; c.reward_type = rt; return c; }
 }
@@ -450,6 +465,118 @@ int xh_cube_cube(int f32, const double *pA, const double *RA, const double *pB, 
         xk::V3<double> A[3], B[3], P[4], N; double D[4]; double lds[xs::LDS_FLOATS]; HostLds<double> hl{lds};
         for (int k = 0; k < 3; k++) { A[k] = xk::mk<double>(RA[k], RA[3 + k], RA[6 + k]); B[k] = xk::mk<double>(RB[k], RB[3 + k], RB[6 + k]); }
         n = xs::cube_cube<double, HostLds<double>>(xk::mk<double>(pA[0], pA[1], pA[2]), A, xk::mk<double>(pB[0], pB[1], pB[2]), B, h, margin, P, N, D, hl);
+        for (int q = 0; q < n; q++) { pts[3 * q] = P[q].x; pts[3 * q + 1] = P[q].y; pts[3 * q + 2] = P[q].z; dist[q] = D[q]; }
+        if (n) { nrm[0] = N.x; nrm[1] = N.y; nrm[2] = N.z; }
+    }
+    return n;
+}
+}
+
+
+// ---- Handover with num_obj = 2 (xarm_handover2_core.h): same two-thread lane-pair emulation
+namespace {
+template <typename T> void h2load(const double *r, int arm, xh2::Lane<T> &L) {
+    for (int i = 0; i < 9; i++) { L.q[i] = (T)r[xh2::G_Q + 9 * arm + i]; L.qd[i] = (T)r[xh2::G_QD + 9 * arm + i]; }
+    L.ft = (T)r[xh2::G_FT + arm];
+    for (int o = 0; o < 2; o++) {
+        for (int k = 0; k < 3; k++) { L.bp[o][k] = (T)r[xh2::G_BP + 3 * o + k]; L.bv[o][k] = (T)r[xh2::G_BV + 3 * o + k]; L.bw[o][k] = (T)r[xh2::G_BW + 3 * o + k]; L.goal[o][k] = (T)r[xh2::G_GOAL + 3 * o + k]; }
+        for (int k = 0; k < 4; k++) L.bq[o][k] = (T)r[xh2::G_BQ + 4 * o + k];
+        for (int k = 0; k < 8; k++) L.lam_t[o][k] = (T)r[xh2::G_LT + 8 * o + k];
+    }
+    for (int k = 0; k < 4; k++) L.lam_p[k] = (T)r[xh2::G_LP + 4 * arm + k];
+    L.touch = (T)r[xh2::G_TOUCH + arm]; L.mug = (T)r[xh2::G_MUG + arm];
+    L.steps = (T)r[xh2::G_STEPS]; L.episode = (T)r[xh2::G_EPISODE];
+}
+template <typename T> void h2store(const xh2::Lane<T> &L, int arm, double *r) {
+    for (int i = 0; i < 9; i++) { r[xh2::G_Q + 9 * arm + i] = L.q[i]; r[xh2::G_QD + 9 * arm + i] = L.qd[i]; }
+    r[xh2::G_FT + arm] = L.ft;
+    for (int k = 0; k < 4; k++) r[xh2::G_LP + 4 * arm + k] = L.lam_p[k];
+    r[xh2::G_TOUCH + arm] = L.touch; r[xh2::G_MUG + arm] = L.mug;
+    if (arm == 0) {
+        for (int o = 0; o < 2; o++) {
+            for (int k = 0; k < 3; k++) { r[xh2::G_BP + 3 * o + k] = L.bp[o][k]; r[xh2::G_BV + 3 * o + k] = L.bv[o][k]; r[xh2::G_BW + 3 * o + k] = L.bw[o][k]; r[xh2::G_GOAL + 3 * o + k] = L.goal[o][k]; }
+            for (int k = 0; k < 4; k++) r[xh2::G_BQ + 4 * o + k] = L.bq[o][k];
+            for (int k = 0; k < 8; k++) r[xh2::G_LT + 8 * o + k] = L.lam_t[o][k];
+        }
+        r[xh2::G_STEPS] = L.steps; r[xh2::G_EPISODE] = L.episode;
+    }
+}
+template <typename T> struct H2Job {
+    int mode; xh::EnvCfg cfg; int64_t E; double *state; const double *act; const uint8_t *mask;
+    double *obs, *ag, *dg, *rew; uint8_t *done, *succ; PairShared *sh; int arm;
+};
+template <typename T> void *h2_thread(void *p) {
+    H2Job<T> &J = *(H2Job<T> *)p;
+    PairXchg x{J.sh, J.arm};
+    for (int64_t e = 0; e < J.E; e++) {
+        if (J.mode == 1 && J.mask && !J.mask[e]) continue;
+        xh2::Lane<T> L; T lds[xh2::LDS_FLOATS]; HostLds<T> hl{lds};
+        h2load(J.state + e * xh2::STATE_DIM, J.arm, L);
+        T r = 0; bool d = false, su = false;
+        if (J.mode == 0) {
+            T a[4]; for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
+            xh2::lane_step<T>(L, J.arm, a, r, d, su, hl, x);
+        } else xh2::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
+        T o8[8];
+        xh2::arm_obs(L, J.arm, o8);
+        J.sh->bar.wait();
+        h2store(L, J.arm, J.state + e * xh2::STATE_DIM);
+        double *o = J.obs + e * xh2::OBS_DIM;
+        for (int k = 0; k < 8; k++) o[26 + 8 * J.arm + k] = o8[k];
+        if (J.arm == 0) {
+            for (int ob = 0; ob < 2; ob++) {
+                for (int k = 0; k < 3; k++) {
+                    o[3 * ob + k] = L.bp[ob][k]; o[14 + 3 * ob + k] = L.bv[ob][k]; o[20 + 3 * ob + k] = L.bw[ob][k];
+                    J.ag[e * 6 + 3 * ob + k] = L.bp[ob][k]; J.dg[e * 6 + 3 * ob + k] = L.goal[ob][k];
+                }
+                for (int k = 0; k < 4; k++) o[6 + 4 * ob + k] = L.bq[ob][k];
+            }
+            if (J.mode == 0) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
+        }
+        J.sh->bar.wait();
+    }
+    return 0;
+}
+template <typename T> void h2_run(int mode, const xh::EnvCfg &cfg, int64_t E, double *state, const double *act, const uint8_t *mask,
+                                  double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    PairShared sh;
+    H2Job<T> j[2];
+    pthread_t th[2];
+    for (int a = 0; a < 2; a++) { j[a] = H2Job<T>{mode, cfg, E, state, act, mask, obs, ag, dg, rew, done, succ, &sh, a}; pthread_create(&th[a], 0, h2_thread<T>, &j[a]); }
+    for (int a = 0; a < 2; a++) pthread_join(th[a], 0);
+}
+}
+extern "C" {
+void xh_ho2_init(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state) {
+    auto c = hcfg(seed, off, ssr, gs);
+    for (int64_t e = 0; e < E; e++) for (int a = 1; a >= 0; a--) {
+        if (f32) { xh2::Lane<float> L; xh2::lane_init<float>(c, e, L); h2store(L, a, state + e * xh2::STATE_DIM); }
+        else { xh2::Lane<double> L; xh2::lane_init<double>(c, e, L); h2store(L, a, state + e * xh2::STATE_DIM); }
+    }
+}
+void xh_ho2_step(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) h2_run<float>(0, c, E, state, act, 0, obs, ag, dg, rew, done, succ); else h2_run<double>(0, c, E, state, act, 0, obs, ag, dg, rew, done, succ);
+}
+void xh_ho2_reset(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) h2_run<float>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0); else h2_run<double>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0);
+}
+// box/box manifold alone with per-box half extents (R row-major, column k = axis k, as the oracle's xo_box_box)
+int xh_box_box(int f32, const double *pA, const double *RA, const double *hA, const double *pB, const double *RB, const double *hB, double margin, double *pts, double *nrm, double *dist) {
+    int n;
+    if (f32) {
+        xk::V3<float> A[3], B[3], P[4], N; float D[4]; float lds[xh2::LDS_FLOATS]; HostLds<float> hl{lds};
+        const float ha[3] = {(float)hA[0], (float)hA[1], (float)hA[2]}, hb[3] = {(float)hB[0], (float)hB[1], (float)hB[2]};
+        for (int k = 0; k < 3; k++) { A[k] = xk::mk<float>((float)RA[k], (float)RA[3 + k], (float)RA[6 + k]); B[k] = xk::mk<float>((float)RB[k], (float)RB[3 + k], (float)RB[6 + k]); }
+        n = xs::box_box<float, HostLds<float>, xh2::LDS_CLIP>(xk::mk<float>((float)pA[0], (float)pA[1], (float)pA[2]), A, ha, xk::mk<float>((float)pB[0], (float)pB[1], (float)pB[2]), B, hb, (float)margin, P, N, D, hl);
+        for (int q = 0; q < n; q++) { pts[3 * q] = P[q].x; pts[3 * q + 1] = P[q].y; pts[3 * q + 2] = P[q].z; dist[q] = D[q]; }
+        if (n) { nrm[0] = N.x; nrm[1] = N.y; nrm[2] = N.z; }
+    } else {
+        xk::V3<double> A[3], B[3], P[4], N; double D[4]; double lds[xh2::LDS_FLOATS]; HostLds<double> hl{lds};
+        const double ha[3] = {hA[0], hA[1], hA[2]}, hb[3] = {hB[0], hB[1], hB[2]};
+        for (int k = 0; k < 3; k++) { A[k] = xk::mk<double>(RA[k], RA[3 + k], RA[6 + k]); B[k] = xk::mk<double>(RB[k], RB[3 + k], RB[6 + k]); }
+        n = xs::box_box<double, HostLds<double>, xh2::LDS_CLIP>(xk::mk<double>(pA[0], pA[1], pA[2]), A, ha, xk::mk<double>(pB[0], pB[1], pB[2]), B, hb, margin, P, N, D, hl);
         for (int q = 0; q < n; q++) { pts[3 * q] = P[q].x; pts[3 * q + 1] = P[q].y; pts[3 * q + 2] = P[q].z; dist[q] = D[q]; }
         if (n) { nrm[0] = N.x; nrm[1] = N.y; nrm[2] = N.z; }
     }

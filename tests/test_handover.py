@@ -226,7 +226,7 @@ def test_gpu_handover_replays_golden_rollout(groll, parity):
 @pytest.mark.gpu
 def test_gpu_handover_16384_properties_and_registry(gref):
     """BASELINE config 5 shard size (131 072 envs over 8 GPUs = 16 384 per GPU): invariants, determinism, shard
-    invariance, auto-reset, batched compute_reward, and the reference's test.py rollout pattern"""
+    invariance, auto-reset, batched compute_reward, and the single-env rollout pattern of the reference's test.py with one stick"""
     import torch
     import gym_xarm_amd as gx
     E = 16384
@@ -257,6 +257,8 @@ def test_gpu_handover_16384_properties_and_registry(gref):
     edge = np.abs(np.linalg.norm(gref["achieved_goal"] - gref["goal"], axis=1) - 0.05) < 1e-6
     assert np.array_equal(out.cpu().numpy()[~edge], gref["reward_batch"][~edge].astype(np.float32))
     env.close()
+    # the single-env call surface with ONE stick (BASELINE config 5's num_obj); the reference's own test.py configuration
+    # (num_obj 2) runs unchanged in tests/test_handover2.py::test_gpu_reference_test_py_runs_unchanged
     one = gx.make("XarmHandover-v0", config={"GUI": False, "num_obj": 1, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False})
     ob = one.reset()
     for i in range(12):

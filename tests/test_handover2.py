@@ -1,0 +1,349 @@
+"""XarmHandover-v0 with config['num_obj'] = 2 - the configuration of the reference's ONLY test (/root/reference/test.py:9-15:
+num_obj 2, goal_shape 'any', same_side_rate 0.5, use_stand False) and of the env file's own __main__
+(xarm_handover.py:448-455).
+
+Pinned to the reference's own NumPy code (tests/golden/handover_reward_reference.npz, keys n2_*): compute_reward in its
+batch and single forms (:177-183), _is_success (:395-402), and the fact that its dense branch raises with two sticks.
+Everything PyBullet computes is oracle-only (parity unpinned): the oracle (oracle/xarm_oracle_handover2.inc.c)
+against the lane-pair kernel core compiled for the host in float64 / float32, and the HIP path through the C ABI.
+Float tolerance (oracle/parity.py): |x - x_oracle| <= 5e-4 + 2e-4 |x| + min(300 sens, 1e-2), discontinuous transitions
+(sens > 1e-2 / 3) exempt and counted."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONT = np.r_[0:36, 38:64]     # q, qd of both arms, pose and velocity of both sticks
+BP0, BP1, GOAL0, GOAL1, TOUCH, LP = slice(38, 41), slice(41, 44), slice(64, 67), slice(67, 70), slice(94, 96), slice(86, 94)
+SUB = [0, 1, 8, 9, 16, 17]    # two envs of each scripted group of the rollout fixture
+
+
+@pytest.fixture(scope="module")
+def gref():
+    return np.load(os.path.join(GOLDEN, "handover_reward_reference.npz"))
+
+
+@pytest.fixture(scope="module")
+def groll():
+    return np.load(os.path.join(GOLDEN, "handover2_oracle_rollout.npz"))
+
+
+# ------------------------------------------------------------------------------------------- reference-pinned
+def test_reward_and_success_match_reference_golden(oracle, gref):
+    env = oracle.OracleHandover(1, num_obj=2)
+    out = env.compute_reward(gref["n2_achieved_goal"], gref["n2_goal"])
+    assert np.array_equal(out, gref["n2_reward_batch"])                         # -sum_i [d_i > 0.05] in {-2, -1, -0} (:177-183)
+    assert np.array_equal(out[:96], gref["n2_reward_single"])                   # the form step() calls (:137)
+    assert np.array_equal((out == 0).astype(float), gref["n2_is_success"])      # AND over the sticks (:395-402)
+    assert set(np.unique(out)) == {-2.0, -1.0, 0.0}
+
+
+def test_dense_reward_is_refused_because_the_reference_raises(gref):
+    """xarm_handover.py:187: grip_pos_1 (3,) - achieved_goal (6,) - recorded from the reference's code by tools/gen_golden.py"""
+    assert int(gref["n2_dense_raises"]) == 1
+    with pytest.raises(ValueError):
+        np.zeros(3) - np.zeros(6) + [0.06, 0, 0]
+    from gym_xarm_amd.vec_env import XarmHandoverVecEnv, HANDOVER_CONFIG_DEFAULTS
+    bare = object.__new__(XarmHandoverVecEnv)
+    with pytest.raises(NotImplementedError, match="187"):
+        bare._check_config(dict(HANDOVER_CONFIG_DEFAULTS, num_obj=2, reward_type="dense"))
+    cfg = bare._check_config({"GUI": False, "num_obj": 2, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False})   # test.py:9-15
+    assert cfg["num_obj"] == 2 and bare.AG_SLICE == slice(0, 6)
+
+
+# ------------------------------------------------------------------------------------------- oracle
+def test_rejection_sampling_invariants(oracle):
+    """_reset_sim :357-360 (second stick: y at least 0.05 from the first stick's y) and _sample_goal :375-379 (second
+    goal: y at least 0.08 from the first goal's y, xy at least 0.08 from the xy of every stick, tested with the goal's x
+    still positive), same-side rule :380-382, 'ground' goals :387-388; counter RNG: stick 0 / goal 0 are the
+    num_obj = 1 draws and the result does not depend on the shard"""
+    js = oracle.load_model_json()["handover"]
+    E = 4096
+    for ssr, shape in ((0.5, "any"), (1.0, "ground"), (0.0, "any")):
+        env = oracle.OracleHandover(E, seed=11, num_obj=2, same_side_rate=ssr, goal_shape=shape)
+        s = env.get_state()        # init = spawn + goals of episode 0, no physics in between: the rules hold exactly
+        assert (np.abs(s[:, 39] - s[:, 42]) >= js["spawn_min_dy"] - 1e-9).all()
+        assert (np.abs(s[:, 65] - s[:, 68]) >= js["goal_min_dy"] - 1e-9).all()
+        g1 = np.column_stack([np.abs(s[:, 67]), s[:, 68]])          # before the side flip
+        for bp in (BP0, BP1):
+            assert (np.linalg.norm(g1 - s[:, bp][:, :2], axis=1) >= js["goal_min_obj_dist"] - 1e-9).all()
+        for bp, hi in ((BP0, js["obj_high"]), (BP1, js["obj_high"])):
+            assert (np.abs(s[:, bp][:, 0]) >= js["obj_low"][0] - 1e-12).all() and (np.abs(s[:, bp][:, 0]) <= hi[0] + 1e-12).all()
+            assert (s[:, bp][:, 1] >= js["obj_low"][1] - 1e-12).all() and (s[:, bp][:, 1] <= hi[1] + 1e-12).all()
+            assert (s[:, bp][:, 2] == js["height_offset"]).all()
+        same0, same1 = np.sign(s[:, 64]) == np.sign(s[:, 38]), np.sign(s[:, 67]) == np.sign(s[:, 41])
+        if ssr == 1.0:
+            assert same0.all() and same1.all() and (s[:, 66] == js["height_offset"]).all() and (s[:, 69] == js["height_offset"]).all()
+        elif ssr == 0.0:
+            assert not same0.any() and not same1.any() and (s[:, 69] > js["height_offset"]).any()
+        else:
+            assert 0.45 < same0.mean() < 0.55 and 0.45 < same1.mean() < 0.55
+            assert 0.45 < (s[:, 41] < 0).mean() < 0.55                # the second stick's own mirror coin (:361-362)
+    one = oracle.OracleHandover(E, seed=11, num_obj=1, same_side_rate=0.0, goal_shape="any").get_state()
+    assert np.array_equal(one[:, 38:41], s[:, BP0]) and np.array_equal(one[:, 51:54], s[:, GOAL0])
+    big = oracle.OracleHandover(8, seed=2, num_obj=2)
+    lo, hi = oracle.OracleHandover(4, seed=2, num_obj=2), oracle.OracleHandover(4, seed=2, num_obj=2, env_id_offset=4)
+    assert np.array_equal(big.state[:4], lo.state) and np.array_equal(big.state[4:], hi.state)
+    # after a real reset (five motor ticks, respawn, one tick) the rules still hold up to the tick's settling motion
+    env = oracle.OracleHandover(256, seed=5, num_obj=2, goal_shape="any")
+    obs, ag, dg = env.reset()
+    s = env.get_state()
+    assert (np.abs(s[:, 39] - s[:, 42]) >= 0.05 - 1e-3).all() and (np.abs(s[:, 65] - s[:, 68]) >= 0.08 - 1e-9).all()
+    assert obs.shape == (256, 42) and np.array_equal(ag, s[:, 38:44]) and np.array_equal(dg, s[:, 64:70])
+    assert (s[:, 98] == 0).all() and (s[:, 99] == 1).all()
+
+
+def test_observation_layout_and_clamp(oracle):
+    """_get_obs :314-329 (pos 6, quat 8, v 6, w 6, then 8 per arm) and the per-stick clamp of _set_action :282-297"""
+    env = oracle.OracleHandover(4, seed=3, num_obj=2)
+    env.reset()
+    st = env.get_state()
+    st[:, 38] = [0.5, -0.5, 0.1, -0.1]; st[:, 39] = [0.3, -0.3, 0.0, 0.0]            # stick 0 outside / inside +-0.28 x +-0.2
+    st[:, 41] = [-0.1, 0.1, -0.6, 0.6]; st[:, 42] = [0.1, 0.1, 0.25, -0.25]          # stick 1
+    st[:, 44:48] = [0.3, 0.4, 0.2, 0.8426]                                           # arbitrary orientations -> pitch only
+    st[:, 48:52] = [0.1, -0.2, 0.5, 0.8307]
+    st[:, 52:64] = 1.0
+    st[:, 98] = [99, 0, 99, 0]
+    env.set_state(st)
+    obs, ag, dg, rew, done, succ = env.step(np.zeros((4, 8)))
+    s = env.get_state()
+    assert done[0] and done[2] and not done[1] and not done[3]                      # TimeLimit(100)
+    assert (np.abs(ag[:, [0, 3]]) <= 0.28 + 0.02).all() and (np.abs(ag[:, [1, 4]]) <= 0.2 + 0.02).all()
+    assert np.abs(s[:, 52:58]).max() < 3.5                                          # the injected 1 m/s was zeroed before the ticks
+    assert np.array_equal(obs[:, 0:6], s[:, 38:44]) and np.array_equal(obs[:, 6:14], s[:, 44:52])
+    assert np.array_equal(obs[:, 14:20], s[:, 52:58]) and np.array_equal(obs[:, 20:26], s[:, 58:64])
+    assert np.array_equal(obs[:, 32], s[:, 7]) and np.array_equal(obs[:, 40], s[:, 16])        # finger joint of arm 1 / arm 2
+    one = oracle.OracleHandover(4, seed=3, num_obj=1)
+    one.reset()
+    s1 = one.get_state()
+    s1[:, 0:36] = s[:, 0:36]
+    one.set_state(s1)
+    o1 = one.step(np.zeros((4, 8)))[0]
+    env.set_state(s)
+    o2 = env.step(np.zeros((4, 8)))[0]
+    np.testing.assert_allclose(o2[:, 26:29], o1[:, 13:16], atol=2e-3)                 # same arm entries as the 29-wide layout
+
+
+def test_stick_on_stick_statics(oracle):
+    """the stick/stick manifold carries load: a stick laid along / across another one rests on it; two sticks pushed
+    together side by side do not interpenetrate"""
+    env = oracle.OracleHandover(3, seed=1, num_obj=2)
+    env.reset()
+    st = env.get_state()
+    st[:, 38:41] = [-0.2, 0.0, 0.025]
+    st[0, 41:44] = [-0.2, 0.0, 0.0755]           # on top, aligned
+    st[1, 41:44] = [-0.17, 0.012, 0.0755]        # on top, offset
+    st[2, 41:44] = [-0.2, 0.047, 0.025]          # side by side, 3 mm of overlap to push out
+    st[:, 44:52] = [0, 0, 0, 1, 0, 0, 0, 1]
+    st[:, 52:64] = 0
+    st[:, 70:94] = 0
+    env.set_state(st)
+    for k in range(10):
+        env.step(np.zeros((3, 8)))
+    s = env.get_state()
+    assert np.allclose(s[:2, 43], 0.075, atol=1.5e-3), s[:2, 43]                    # resting on the lower stick
+    assert np.allclose(s[:, 40], 0.025, atol=1e-3)
+    assert abs(s[2, 42] - s[2, 39]) >= 0.05 - 1e-3                                  # pushed apart to touching
+    assert np.isfinite(s).all()
+
+
+def test_fixture_covers_the_contact_regimes(oracle, groll):
+    S = groll["states"]
+    assert (S[1:-6, :8, 43] > 0.06).mean() > 0.5                                     # stick 1 carried by stick 0 for most of the script
+    assert (S[:, 8:16, 94] > 0).any(axis=0).all()                                    # arm 1 grasps stick 0 in every env of group 2
+    held = (S[:, 16:, 86:90] > 0).any(axis=2)                                        # arm 1's pads press on stick 1 ...
+    assert held.any(axis=0).all() and S[:, 16:, 94][held].mean() < 0.05              # ... and the grasp flag (stick 0 only, :263) stays clear
+    # the stick/stick manifold is non-empty in a good share of the recorded states
+    n = 0
+    h = np.array(oracle.load_model_json()["handover"]["obj_half"])
+    for t in range(0, S.shape[0], 5):
+        for e in range(16):
+            s = S[t, e]
+            R = [_quat_R(s[44 + 4 * o:48 + 4 * o]) for o in range(2)]
+            n += len(oracle.box_box(s[38:41], R[0], h, s[41:44], R[1], h, 0.005)[2]) > 0
+    assert n > 40
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+# ------------------------------------------------------------------------------------------- kernel core on the host
+def test_box_box_with_stick_extents_matches_oracle(oracle, hostcore):
+    rng = np.random.default_rng(4)
+    h = np.array([0.075, 0.025, 0.025])
+    n_face = n_edge = 0
+    for k in range(300):
+        qa, qb = rng.normal(size=4), rng.normal(size=4)
+        if k % 3 == 0:
+            qa, qb = np.array([0, np.sin(0.1 * rng.normal()), 0, 1.0]), np.array([0, np.sin(0.1 * rng.normal()), 0, 1.0])   # pitch only, as after the clamp
+        RA, RB = _quat_R(qa / np.linalg.norm(qa)), _quat_R(qb / np.linalg.norm(qb))
+        pA = rng.uniform(-0.05, 0.05, 3)
+        pB = pA + rng.uniform(-1, 1, 3) * [0.12, 0.05, 0.05]
+        po, no, do = oracle.box_box(pA, RA, h, pB, RB, h, 0.005)
+        ph, nh, dh = hostcore.box_box(pA, RA, h, pB, RB, h, 0.005, f32=0)
+        assert len(do) == len(dh), k
+        if len(do):
+            np.testing.assert_allclose(ph, po, atol=1e-12)
+            np.testing.assert_allclose(nh, no, atol=1e-12)
+            np.testing.assert_allclose(dh, do, atol=1e-12)
+            n_face += len(do) > 1
+            n_edge += len(do) == 1
+    assert n_face > 30 and n_edge > 5
+
+
+def test_hostcore_lane_pair_f64_equals_oracle(hostcore, groll):
+    g = groll
+    st = hostcore.ho2_init(24, f32=0, seed=2, gs=0)
+    np.testing.assert_allclose(st, g["init_state"], atol=1e-15)
+    st, obs, ag, dg = hostcore.ho2_reset(st[:6], f32=0, seed=2, gs=0)
+    np.testing.assert_allclose(st, g["reset_state"][:6], atol=1e-9)
+    np.testing.assert_allclose(obs, g["reset_obs"][:6], atol=1e-9)
+    n_ok = n_all = 0
+    for t in range(0, g["actions"].shape[0], 3):
+        st, obs, ag, dg, rew, done, succ = hostcore.ho2_step(g["states"][t][SUB], g["actions"][t][SUB], f32=0, seed=2, gs=0)
+        sens = g["sens"][t][SUB]
+        ok = sens < 1e-2
+        err = np.abs(st - g["states"][t + 1][SUB]).max(axis=1)
+        assert (err[ok] <= 1e-8 + 1e-3 * sens[ok]).all(), (t, err[ok].max())
+        np.testing.assert_allclose(obs[ok], g["obs"][t][SUB][ok], atol=1e-7)
+        assert np.array_equal(rew[ok], g["rew"][t][SUB][ok]) and np.array_equal(done[ok], g["done"][t][SUB][ok])
+        assert np.array_equal(st[ok][:, TOUCH], g["states"][t + 1][SUB][ok][:, TOUCH])
+        n_ok += ok.sum()
+        n_all += ok.size
+    assert n_ok > 0.8 * n_all
+
+
+def test_hostcore_lane_pair_f32_within_tolerance(hostcore, groll, parity):
+    g = groll
+    for t in range(1, g["actions"].shape[0], 7):
+        st, *_ = hostcore.ho2_step(g["states"][t], g["actions"][t], f32=1, seed=2, gs=0)
+        parity.compare(st[:, CONT], g["states"][t + 1][:, CONT], g["sens"][t], what="handover2 f32 t=%d" % t, frac_tight=0.7, max_exempt=0.3)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_handover2_replays_golden_rollout(groll, parity):
+    import torch
+    import gym_xarm_amd as gx
+    g = groll
+    E = g["states"].shape[1]
+    cfg = {"GUI": False, "num_obj": 2, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False}      # test.py:9-15
+    env = gx.make("XarmHandover-v0", num_envs=E, seed=2, auto_reset=False, config=cfg)
+    assert env.obs_dim == 42 and env.goal_dim == 6 and env.state_dim == 100 and env.act_dim == 8
+    np.testing.assert_allclose(env.get_state().cpu().numpy(), g["init_state"], atol=1e-6)
+    obs = env.reset()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(obs["observation"].cpu().numpy(), g["reset_obs"], atol=3e-3)
+    np.testing.assert_allclose(obs["desired_goal"].cpu().numpy(), g["reset_state"][:, 64:70], atol=1e-6)
+    np.testing.assert_allclose(env.get_state().cpu().numpy()[:, CONT], g["reset_state"][:, CONT], atol=3e-3)
+    n_tight = n = flags = held1 = 0
+    for t in range(g["actions"].shape[0]):
+        env.set_state(g["states"][t])
+        obs, rew, done, info = env.step(torch.tensor(g["actions"][t], dtype=torch.float32))
+        st = env.get_state().cpu().numpy().astype(np.float64)
+        sens = g["sens"][t]
+        stats = parity.compare(st[:, CONT], g["states"][t + 1][:, CONT], sens, what="handover2 gpu t=%d" % t, frac_tight=0.6, max_exempt=0.35)
+        n_tight += stats["frac_tight"] * E
+        n += E
+        ok = sens < 1e-3
+        np.testing.assert_allclose(obs["observation"].cpu().numpy()[ok], g["obs"][t][ok], atol=3e-3)
+        np.testing.assert_allclose(obs["achieved_goal"].cpu().numpy()[ok], g["states"][t + 1][ok][:, 38:44], atol=3e-3)
+        assert np.array_equal(rew.cpu().numpy()[ok], g["rew"][t][ok].astype(np.float32))
+        assert np.array_equal(done.cpu().numpy()[ok], g["done"][t][ok])
+        assert np.array_equal(st[ok][:, TOUCH], g["states"][t + 1][ok][:, TOUCH])          # per-arm grasp flags (stick 0 only)
+        flags += st[ok][:, 94].sum()
+        held1 += (st[ok][16:, 86:90] > 0).any(axis=1).sum() if ok[16:].any() else 0
+    assert n_tight >= 0.8 * n and flags > 20 and held1 > 20       # the contact regimes were really exercised
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_handover2_reset_sampling_and_properties(oracle, gref):
+    """4 096 envs through the C ABI: the device's rejection sampling obeys the reference's spacing rules and equals the
+    oracle's draws; determinism, shard invariance, auto-reset, invariants, batched compute_reward"""
+    import torch
+    import gym_xarm_amd as gx
+    E = 4096
+    cfg = {"GUI": False, "num_obj": 2, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False}
+    env = gx.make("XarmHandover-v0", num_envs=E, seed=11, config=cfg)
+    s = env.get_state().cpu().numpy().astype(np.float64)
+    ora = oracle.OracleHandover(E, seed=11, num_obj=2, goal_shape="any")
+    np.testing.assert_allclose(s, ora.get_state(), atol=1e-6)                    # same accepted attempts, float32 rounding only
+    assert (np.abs(s[:, 39] - s[:, 42]) >= 0.05 - 1e-6).all() and (np.abs(s[:, 65] - s[:, 68]) >= 0.08 - 1e-6).all()
+    g1 = np.column_stack([np.abs(s[:, 67]), s[:, 68]])
+    for bp in (BP0, BP1):
+        assert (np.linalg.norm(g1 - s[:, bp][:, :2], axis=1) >= 0.08 - 1e-6).all()
+    obs = env.reset()
+    s = env.get_state().cpu().numpy().astype(np.float64)
+    ora.reset()
+    so = ora.get_state()
+    assert np.median(np.abs(s[:, CONT] - so[:, CONT]).max(axis=1)) < 2e-4       # six ticks from the same start
+    assert (np.abs(s[:, 64:70] - so[:, 64:70]).max(axis=1) < 1e-5).mean() > 0.999   # goals: same attempts up to a tie on a boundary
+    assert (np.abs(s[:, 39] - s[:, 42]) >= 0.05 - 1e-3).all()
+    acts = [torch.rand(E, 8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(k)) * 2 - 1 for k in range(3)]
+
+    def run(n, off):
+        e = gx.make("XarmHandover-v0", num_envs=n, seed=6, env_id_offset=off, config=cfg)
+        e.reset()
+        for k in range(3):
+            o, r, d, i = e.step(acts[k][off:off + n])
+        out = e.get_state().clone(), o["observation"].clone(), r.clone()
+        e.close()
+        return out
+    full, again, half = run(E, 0), run(E, 0), run(E // 2, E // 2)
+    for x, y, z in zip(full, again, half):
+        assert torch.equal(x, y) and torch.equal(x[E // 2:], z)
+    st = full[0]
+    assert torch.isfinite(st).all()
+    for o in range(2):
+        assert ((st[:, 44 + 4 * o:48 + 4 * o].norm(dim=1) - 1).abs() < 1e-5).all()
+    assert ((full[2] == 0) | (full[2] == -1) | (full[2] == -2)).all()
+    # auto-reset at the time limit
+    sm = env.get_state()
+    sm[:64, 98] = 99
+    env.set_state(sm)
+    obs, rew, done, info = env.step(torch.zeros(E, 8))
+    s2 = env.get_state()
+    assert done[:64].all() and (s2[:64, 98] == 0).all() and (s2[:64, 99] == 2).all() and not done[64:].any()
+    assert info["terminal_observation"].shape == (E, 42)
+    out = env.compute_reward(torch.tensor(gref["n2_achieved_goal"], dtype=torch.float32), torch.tensor(gref["n2_goal"], dtype=torch.float32))
+    d = np.stack([np.linalg.norm((gref["n2_achieved_goal"] - gref["n2_goal"])[:, 3 * o:3 * o + 3], axis=1) for o in range(2)])
+    edge = (np.abs(d - 0.05) < 1e-6).any(axis=0)
+    assert np.array_equal(out.cpu().numpy()[~edge], gref["n2_reward_batch"][~edge].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_test_py_runs_unchanged():
+    """/root/reference/test.py:9-29 with its literal config: gym.make('XarmHandover-v0', config=config), a random-action
+    rollout with space-containment asserts, reset every _max_episode_steps; run for _max_episode_steps + 5 steps"""
+    import gym_xarm_amd as gx
+    config = {
+        'GUI': False,              # the one key changed: the reference opens a GUI window (out of scope)
+        'num_obj': 2,
+        'same_side_rate': 0.5,
+        'goal_shape': 'any',
+        'use_stand': False,
+    }
+    env = gx.make('XarmHandover-v0', config=config)
+    assert env.observation_space["observation"].shape == (42,) and env.observation_space["achieved_goal"].shape == (6,)
+    assert env._max_episode_steps == 100
+    agent = lambda ob: env.action_space.sample()      # noqa: E731 (as test.py:17)
+    ob = env.reset()
+    for i in range(env._max_episode_steps + 5):
+        assert env.observation_space.contains(ob)
+        a = agent(ob)
+        assert env.action_space.contains(a)
+        (ob, _reward, done, _info) = env.step(a)
+        assert _reward in (0.0, -1.0, -2.0) and isinstance(done, bool) and _info["is_success"] in (0.0, 1.0)
+        assert np.isfinite(ob["observation"]).all()
+        r = env.compute_reward(ob["achieved_goal"], ob["desired_goal"], _info)
+        assert r == _reward
+        if i % env._max_episode_steps == 0:
+            ob = env.reset()
+    env.close()

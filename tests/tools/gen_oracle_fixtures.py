@@ -197,7 +197,93 @@ def handover():
           "handed over:", int(((st[:, 38] * states[0][:, 38] < 0) | (st[:, 40] > 0.08)).sum()), "of", E, "max sens %.2e" % np.max(sens_l))
 
 
+def _ez_on(o, k):
+    """_ezpolicy steering at stick k of a num_obj = 2 observation (42 wide: pos 6, quat 8, v 6, w 6, arms 16)"""
+    o29 = np.concatenate([o[3 * k:3 * k + 3], o[6 + 4 * k:10 + 4 * k], o[14 + 3 * k:17 + 3 * k], o[20 + 3 * k:23 + 3 * k], o[26:42]])
+    return _ezpolicy(o29)
+
+
+HO2_CONT = np.r_[0:36, 38:64]   # q, qd of both arms, pose and velocity of both sticks
+
+
+def ho2_sens(ora, s0, a, nxt, seed):
+    E = s0.shape[0]
+    sens = np.zeros(E)
+    for k in range(2):
+        sp = s0.copy()
+        sp[:, HO2_CONT] += np.random.default_rng(1000 * seed + k).uniform(-1e-6, 1e-6, size=(E, HO2_CONT.size))
+        for o in range(2):
+            qn = sp[:, 44 + 4 * o:48 + 4 * o]
+            sp[:, 44 + 4 * o:48 + 4 * o] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+        ora.set_state(sp)
+        ora.step(a)
+        sens = np.maximum(sens, np.abs(ora.get_state()[:, HO2_CONT] - nxt[:, HO2_CONT]).max(1))
+    return sens
+
+
+def handover2():
+    """XarmHandover-v0 with num_obj = 2 (the reference's test.py configuration): 24 envs, 30 scripted + 6 random steps.
+    Envs 0-7: stick 1 laid across the top of stick 0 (stick/stick manifold under load) with small random arm motion;
+    8-15: the two sticks side by side and touching on arm 1's side, the reference's ezpolicy steering at stick 0 (grasp
+    flags set, stick 0 dragged against stick 1); 16-23: ezpolicy steering at stick 1 with stick 0 out of the way (pads hold
+    stick 1: the grasp flags, which read contacts with stick 0 only, must stay clear)."""
+    E = 24
+    ora = O.OracleHandover(E, seed=2, num_obj=2, goal_shape="any")
+    init = ora.get_state()
+    obs = ora.reset()[0]
+    reset_state, reset_obs = ora.get_state(), obs.copy()
+    rng = np.random.default_rng(9)
+    st = ora.get_state()
+    for e in range(E):
+        j = rng.uniform(-1, 1, 4)
+        if e < 8:
+            st[e, 38:41] = [-0.19 + 0.03 * j[0], 0.05 * j[1], 0.025]
+            st[e, 41:44] = [st[e, 38] + 0.03 * j[2], st[e, 39] + 0.012 * j[3], 0.0752]
+        elif e < 16:
+            st[e, 38:41] = [-0.2 + 0.03 * j[0], 0.04 * j[1], 0.025]
+            st[e, 41:44] = [st[e, 38] + 0.02 * j[2], st[e, 39] + (0.05 + 0.001 * j[3]) * (1 if e % 2 else -1), 0.025]
+        else:
+            st[e, 38:41] = [0.2 + 0.03 * j[0], 0.1 * j[1], 0.025]
+            st[e, 41:44] = [-0.2 + 0.03 * j[2], 0.05 * j[3], 0.025]
+        st[e, 44:52] = [0, 0, 0, 1, 0, 0, 0, 1]
+        st[e, 52:64] = 0
+        st[e, 70:94] = 0
+    ora.set_state(st)
+    obs = np.zeros((E, 42))
+    z8 = np.zeros((E, 8))
+    obs = ora.step(z8)[0]          # one quiet step so that the scripted scene has settled contact impulses
+    states, acts, obs_l, rew_l, done_l, succ_l, sens_l = [ora.get_state()], [], [], [], [], [], []
+    for t in range(36):
+        if t < 30:
+            a = np.zeros((E, 8))
+            a[:8] = rng.uniform(-0.3, 0.3, (8, 8))
+            a[8:16] = [_ez_on(obs[e], 0) for e in range(8, 16)]
+            a[16:] = [_ez_on(obs[e], 1) for e in range(16, E)]
+        else:
+            a = rng.uniform(-1, 1, (E, 8))
+        s0 = states[-1]
+        ora.set_state(s0)
+        o = ora.step(a)
+        nxt = ora.get_state()
+        sens = ho2_sens(ora, s0, a, nxt, t)
+        ora.set_state(nxt)
+        obs = o[0]
+        states.append(nxt); acts.append(a); obs_l.append(o[0]); rew_l.append(o[3]); done_l.append(o[4]); succ_l.append(o[5]); sens_l.append(sens)
+    path = os.path.join(ROOT, "tests", "golden", "handover2_oracle_rollout.npz")
+    S = np.stack(states)
+    np.savez_compressed(path, init_state=init, reset_state=reset_state, reset_obs=reset_obs, actions=np.stack(acts), states=S,
+                        obs=np.stack(obs_l), rew=np.stack(rew_l), done=np.stack(done_l), succ=np.stack(succ_l), sens=np.stack(sens_l))
+    print("wrote", path, "| stick 1 still on stick 0 at the end:", int((S[-7, :8, 43] > 0.06).sum()), "of 8",
+          "| grasp flag arm 1 ever set (8-15):", int((S[:, 8:16, 94] > 0).any(0).sum()), "of 8",
+          "| pad impulses on stick 1 (16-23):", int((S[:, 16:, 86:90] > 0).any(2).any(0).sum()), "of 8, grasp flags there:", int(S[:, 16:, 94:96].sum()),
+          "| max sens %.2e, share < 1e-3: %.2f" % (np.max(sens_l), np.mean(np.stack(sens_l) < 1e-3)))
+
+
 if __name__ == "__main__":
+    if "handover2" in sys.argv:
+        handover2()
+        sys.exit(0)
     main()
     reach()
     handover()
+    handover2()

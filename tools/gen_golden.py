@@ -203,6 +203,33 @@ def handover():
     assert raised.sum() == ((~if1) & if2).sum() and raised.sum() > 20
     out.update(dense_hand_com_1=hand1, dense_hand_com_2=hand2, dense_if_1=if1.astype(np.uint8), dense_if_2=if2.astype(np.uint8),
                dense_achieved_goal=agd, dense_goal=gd, dense_reward=dense, dense_reference_raises=raised)
+    # num_obj = 2 (the reference's own test configuration, test.py:9-15): rows of 6 = two sticks; its own generator so that
+    # the arrays above stay what they were
+    rng2 = np.random.default_rng(778)
+    n2 = 512
+    g2 = rng2.uniform([-0.28, -0.18, 0.025] * 2, [0.28, 0.18, 0.2] * 2, size=(n2, 6))
+    ag2 = g2.copy()
+    for o in range(2):
+        d = rng2.normal(size=(n2, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r = np.concatenate([rng2.uniform(0, 0.3, n2 // 4), 0.05 + rng2.uniform(-2e-3, 2e-3, n2 // 4), rng2.uniform(0, 0.05, n2 - 2 * (n2 // 4))])
+        ag2[:, 3 * o:3 * o + 3] += d * rng2.permutation(r)[:, None]
+    self2 = SimpleNamespace(reward_type="sparse", distance_threshold=0.05, config={"num_obj": 2})
+    out["n2_achieved_goal"], out["n2_goal"] = ag2, g2
+    out["n2_reward_batch"] = np.asarray(cls.compute_reward(self2, ag2, g2, {}))                       # :177-183 batch form
+    out["n2_reward_single"] = np.array([cls.compute_reward(self2, ag2[i], g2[i], {}) for i in range(96)])  # as step() calls it (:137)
+    out["n2_is_success"] = np.array([cls._is_success(self2, ag2[i], g2[i]) for i in range(n2)])            # :395-402
+    assert set(np.unique(out["n2_reward_batch"])) == {0.0, -1.0, -2.0} and 0 < out["n2_is_success"].mean() < 1
+    # the dense branch cannot run with two sticks: (3,) grip position minus the (6,) achieved_goal (:187)
+    fake.hand[1], fake.hand[2] = hand1[0], hand2[0]
+    selfd = SimpleNamespace(reward_type="dense", distance_threshold=0.05, config={"num_obj": 2}, _p=fake, xarm_1=1, xarm_2=2,
+                            gripper_base_index=9, eef2grip_offset=[0, 0, 0.088 - 0.021], if_xarm1_grasp=False, if_xarm2_grasp=False)
+    try:
+        cls.compute_reward(selfd, ag2[0], g2[0], {})
+        out["n2_dense_raises"] = np.uint8(0)
+    except ValueError:
+        out["n2_dense_raises"] = np.uint8(1)
+    assert out["n2_dense_raises"] == 1
     np.savez(os.path.join(OUT, "handover_reward_reference.npz"), **out)
     print("wrote handover_reward_reference.npz")
 

@@ -2,7 +2,8 @@
 """Headline benchmark: env steps/sec of XarmPDPickAndPlace-v0 (BASELINE.json `metric`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack]
-                  [--scaling weak|strong] [--repeats R] [--episode-phase desync|lockstep]
+                  [--scaling weak|strong] [--repeats R] [--episode-phase desync|lockstep] [--aged-preroll P]
+                  [--no-aged] [--no-lockstep] [--no-lazy] [--no-strong] [--no-extras] [--no-cpu-baseline]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one env step of EVERY environment of the job (one xarm_step call per rank), including
@@ -18,6 +19,16 @@ their steady-state rate (E / max_episode_steps per step) instead of all E at onc
 counters as reset() leaves them; the default `auto` picks the workload's own steady state - desync where an episode can
 end early by success (pnp, handover), lockstep where every episode has the same fixed length (reach, stack).
 Rank 0 prints ONE JSON line.
+
+Besides `value` (the K timed steps right after the W warm-up steps) the line carries, each measured by the same
+three-window protocol and never feeding `value`:
+  aged_state      the same handle after an untimed pre-roll of --aged-preroll (default 1 000) further steps: random actions
+                  knock the objects about, reset wavefronts then carry finger-contact rows through their ticks - the rate a
+                  long-running user sees (skip: --no-aged);
+  strong_scaling  only when world > 1 under weak scaling: the configured env count (65 536) as the TOTAL, split over the
+                  ranks by shard_range - the other reading of "65 536 parallel envs at 1/2/4/8 GPUs" (skip: --no-strong);
+  lockstep_phase  episodes in lockstep from reset() (skip: --no-lockstep); lazy_reset: the opt-in lazy auto-reset (--no-lazy).
+--no-extras skips all four (what the profiling scripts use).
 
 `--workload` selects one of the other BASELINE.json configs for the same measurement (same JSON schema, its own
 metric name): reach = config 2 (XarmReach-v0, 4 096 envs), stack = config 4 (XarmPDStackTower-v0, 8 192 envs per
@@ -139,7 +150,14 @@ def main():
     ap.add_argument("--episode-phase", choices=["auto", "desync", "lockstep"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the extra measurement of the opt-in lazy auto-reset mode")
+    ap.add_argument("--no-lockstep", action="store_true", help="skip the lockstep-phase leg")
+    ap.add_argument("--no-aged", action="store_true", help="skip the aged-state leg (pre-roll + the same windows)")
+    ap.add_argument("--aged-preroll", type=int, default=1000, help="untimed steps before the aged-state windows")
+    ap.add_argument("--no-strong", action="store_true", help="world > 1: skip the strong-scaling leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip every leg that does not feed `value`")
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_lazy = args.no_lockstep = args.no_aged = args.no_strong = True
 
     import torch
     import torch.distributed as dist
@@ -190,6 +208,8 @@ def main():
     ring = [torch.rand(E, act_dim, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     env.reset()
     T_ep = env.max_episode_steps
+    env_state_dim = getattr(env, "state_dim", 0)
+    env_out_floats = getattr(env, "obs_dim", 0) + 2 * getattr(env, "goal_dim", 0)
     # which kernel family this handle runs (include/xarm_hip.h xarm_kernel_limits): the cooperative kernels serve batches
     # / reset lists up to the limits, the one-env-per-lane kernels the rest
     reset_limit, step_limit = env.kernel_limits() if hasattr(env, "kernel_limits") else (0, 0)
@@ -210,19 +230,60 @@ def main():
         obs, rew, done, info = env.step(ring[i % 64])
         n_done += done.sum()
     sync()
-    windows = []
-    for r in range(max(1, args.repeats)):
-        windows.append(timed_window(env, ring, args.warmup + r * args.steps, args.steps, world, dev, dist, D, torch, sync))
+    def measure(e, first):
+        """`--repeats` back-to-back windows of --steps calls; returns (all windows, the median one)"""
+        ws = [timed_window(e, ring_of[id(e)], first + r * args.steps, args.steps, world, dev, dist, D, torch, sync) for r in range(max(1, args.repeats))]
+        order = sorted(range(len(ws)), key=lambda k: ws[k][0])
+        return ws, ws[order[len(order) // 2]]
+
+    ring_of = {id(env): ring}
+    windows, (dt, resets, kstep_ms, reset_ms, launches) = measure(env, args.warmup)
     total_envs = int(D.sum_over_ranks(E, device=dev))
-    order = sorted(range(len(windows)), key=lambda k: windows[k][0])
-    dt, resets, kstep_ms, reset_ms, launches = windows[order[len(order) // 2]]     # the median window
+
+    # extra: the same handle, aged.  An untimed pre-roll, then the same windows.  Random actions knock the objects about,
+    # so the slowest reset wavefront of a call carries finger-contact rows through its six ticks (DESIGN.md 6).
+    aged = None
+    if not args.no_aged and args.aged_preroll > 0:
+        for i in range(args.aged_preroll):
+            env.step(ring[i % 64])
+        sync()
+        aw, (adt, aresets, akstep, areset, _) = measure(env, args.aged_preroll)
+        aged = {"value": total_envs * args.steps / adt, "unit": "env steps/s", "preroll_steps": args.aged_preroll + args.warmup + args.steps * len(windows),
+                "ms_per_step": adt / args.steps * 1e3, "step_kernel_ms": akstep, "reset_kernels_ms": areset,
+                "resets_per_step": aresets / args.steps,
+                "env_steps_per_sec": [total_envs * args.steps / w[0] for w in aw],
+                "note": "same handle and protocol as `value`, after the untimed pre-roll: the rate of a long run"}
+
+    # extra (world > 1, weak scaling): the configured env count as the TOTAL of the job, split over the ranks
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        slo, shi = D.shard_range(n_cfg, rank, world)
+        senv = make(env_id, num_envs=shi - slo, seed=0, env_id_offset=slo, device=dev, config=env_config)
+        sring = [r[:shi - slo] for r in ring]
+        ring_of[id(senv)] = sring
+        senv.reset()
+        if args.episode_phase == "desync":
+            senv.set_episode_steps((torch.arange(shi - slo, device=dev) + slo) * 7919 % T_ep)
+        for i in range(args.warmup):
+            senv.step(sring[i % 64])
+        sync()
+        sw, (sdt, sres, skstep, sreset, _) = measure(senv, args.warmup)
+        s_lim = senv.kernel_limits() if hasattr(senv, "kernel_limits") else (0, 0)
+        strong = {"value": n_cfg * args.steps / sdt, "unit": "env steps/s", "total_envs": n_cfg, "envs_per_gpu": shi - slo,
+                  "shard_range_rank0": [int(slo), int(shi)], "ms_per_step": sdt / args.steps * 1e3,
+                  "step_kernel_ms": skstep, "reset_kernels_ms": sreset,
+                  "step_kernel": COOP_STEP_KERNEL[args.workload] if args.workload in COOP_STEP_KERNEL and (shi - slo) <= s_lim[1] else WORKLOADS[args.workload][4],
+                  "env_steps_per_sec": [n_cfg * args.steps / w[0] for w in sw],
+                  "note": "strong scaling: %d envs in TOTAL split by shard_range; a step call is latency-bound, so this grows "
+                          "far slower than the weak-scaling `value` (DESIGN.md 7)" % n_cfg}
+        senv.close()
 
     # extra (workloads measured with desynchronised phases): the same env started in lockstep - every episode from
     # reset() together, the time-limit resets arriving as one bulk reset every T_ep-th step, which is what a caller sees
     # until early successes spread the phases.  Never feeds `value`; timed over whole episodes (>= 2 * T_ep steps) so
     # that the window holds its share of bulk resets whatever --steps is.
     lockstep = None
-    if args.episode_phase == "desync" and not args.no_lazy and hasattr(env, "set_episode_steps"):
+    if args.episode_phase == "desync" and not args.no_lockstep and hasattr(env, "set_episode_steps"):
         env.close()
         kenv = make(env_id, num_envs=E, seed=0, env_id_offset=offset, device=dev, config=env_config)
         kenv.reset()
@@ -298,22 +359,45 @@ def main():
         # secondary ceiling (the one that actually binds): fp32 vector issue.  FLOPs per env step are COUNTED (the
         # kernel core instantiated with a counting scalar type, tools/count_flops.py -> profiles/flop_count.json);
         # the wave-instruction count of the committed SQ_INSTS_VALU pass is kept beside it
+        # secondary ceiling (the one that actually binds): fp32 vector issue.  FLOPs are COUNTED (the kernel core
+        # instantiated with a counting scalar type, tools/count_flops.py -> profiles/flop_count.json): per env step for the
+        # step kernel and, where counted (pnp), per reset for the reset kernels - both over the HIP-event time of the call
         valu = None
         flops = pmc_data.get("%s_counted_flops_per_env_step" % args.workload)
+        flops_reset = pmc_data.get("%s_counted_flops_per_env_reset" % args.workload)
         n_valu = pmc_data.get("%s_valu_wave_insts_per_launch_%d" % (kernel_name, E))
+        resets_per_call = resets / max(args.steps, 1) / world
         if flops:
-            tf = flops * E / (call_ms * 1e-3) / 1e12
-            valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (counted flops per env step x env steps / kernel time)",
-                    "frac": tf / VALU_PEAK_TFLOPS, "counted_flops_per_env_step": flops}
+            tf_step = flops * E / (kstep_ms * 1e-3) / 1e12
+            valu = {"unit": "TFLOP/s (counted flops / HIP-event kernel time)", "peak": VALU_PEAK_TFLOPS,
+                    "step_kernel": {"achieved": tf_step, "frac": tf_step / VALU_PEAK_TFLOPS, "counted_flops_per_env_step": flops}}
+            if flops_reset and reset_ms > 0:
+                tf_reset = flops_reset * resets_per_call / (reset_ms * 1e-3) / 1e12
+                tf_call = (flops * E + flops_reset * resets_per_call) / (call_ms * 1e-3) / 1e12
+                valu["reset_kernels"] = {"achieved": tf_reset, "frac": tf_reset / VALU_PEAK_TFLOPS, "counted_flops_per_env_reset": flops_reset,
+                                         "resets_per_call": resets_per_call}
+                valu["achieved"], valu["frac"], valu["covers"] = tf_call, tf_call / VALU_PEAK_TFLOPS, "step + reset kernels of one xarm_step call"
+            else:
+                valu["achieved"], valu["frac"], valu["covers"] = tf_step, tf_step / VALU_PEAK_TFLOPS, "step kernel only (reset flops not counted for this workload)"
             if n_valu:
                 valu["wave_insts_per_step_kernel_launch"] = n_valu
         elif n_valu:
             tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
             valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction, step kernel only)",
-                    "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu}
+                    "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu, "covers": "step kernel only"}
+        reset_kernel_key = {"pnp": "k_reset_coop", "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
+                            "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
         reset_kernel = {"pnp": "k_reset_coop (<= %d finished envs per call) / k_reset" % reset_limit,
                         "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
                         "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
+        # reset kernels: algorithmic bytes = state in + out and the fresh obs / goal rows, per finished env
+        reset_algo = resets_per_call * (2 * 4 * env_state_dim + 4 * env_out_floats)
+        reset_traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (reset_kernel_key, E))
+        reset_entry = {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms, "resets_per_call": resets_per_call,
+                       "algorithmic_bytes_per_launch": reset_algo, "traffic": reset_traffic}
+        if reset_ms > 0:
+            reset_entry["achieved_GBs"] = reset_algo / (reset_ms * 1e-3) / 1e9
+            reset_entry["frac"] = reset_entry["achieved_GBs"] / HBM_PEAK_GBS
         out = {
             "metric": "env steps/sec (whole node), %s" % env_id, "value": value, "unit": "env steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -329,21 +413,27 @@ def main():
                         "max": total_envs * args.steps / min(w[0] for w in windows)},
             # the unit of work is one xarm_step call = step kernel + the reset kernels that follow it; SURVEY 8(d)'s
             # algorithmic bytes per env step x E env steps per call, over the HIP-event time of those kernels
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names what binds (fp32 VALU issue / dependent-instruction latency of lone wavefronts);
+            # achieved / peak / frac / traffic are the HBM figures the contract asks for - a fused step touches HBM once
+            "roofline": {"bound": "valu/latency", "reported_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "%s + %s (one xarm_step call)" % (kernel_name, reset_kernel),
                          "kernel_avg_ms": call_ms, "kernel_launches": int(launches),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernels": {kernel_name: {"avg_ms": kstep_ms, "share": kstep_ms / call_ms,
-                                                   "achieved_GBs": step_only, "frac": step_only / HBM_PEAK_GBS},
-                                     "reset": {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms}},
+                                                   "achieved_GBs": step_only, "frac": step_only / HBM_PEAK_GBS, "traffic": traffic},
+                                     "reset": reset_entry},
                          "dominant_kernel": kernel_name if kstep_ms >= reset_ms else reset_kernel,
-                         "note": "fused step: HBM is touched once per env step, the kernels are fp32-VALU/latency bound (DESIGN.md); "
-                                 "`traffic` is the PMC figure of the step kernel"},
+                         "note": "fused step: HBM is touched once per env step, the kernels are fp32-VALU/latency bound (DESIGN.md 5); "
+                                 "`traffic` is the PMC figure of the step kernel, kernels.reset.traffic that of the reset kernel"},
             "kernel_only_env_steps_per_sec_per_gpu": E / (call_ms * 1e-3),
         }
         if valu is not None:
             out["roofline"]["valu"] = valu
+        if aged is not None:
+            out["aged_state"] = aged
+        if strong is not None:
+            out["strong_scaling"] = strong
         if lockstep is not None:
             out["lockstep_phase"] = lockstep
         if lazy is not None:

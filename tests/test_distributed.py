@@ -94,7 +94,7 @@ def test_bench_rank_plumbing_two_ranks_gloo(tmp_path, scaling):
                XARM_BENCH_STUB_LOG=log, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
-           "--envs-per-gpu", "101", "--scaling", scaling, "--repeats", "2", "--no-cpu-baseline"]
+           "--envs-per-gpu", "101", "--scaling", scaling, "--repeats", "2", "--no-cpu-baseline", "--aged-preroll", "25"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
@@ -108,9 +108,25 @@ def test_bench_rank_plumbing_two_ranks_gloo(tmp_path, scaling):
     else:
         assert d["config"]["total_envs"] == 101 and [s[0]["num_envs"] for s in shards] == [51, 50]      # shard_range
         assert [s[0]["env_id_offset"] for s in shards] == [0, 51]
-    assert all(s[1]["auto_reset"] == "True" and s[1]["num_envs"] == s[0]["num_envs"] for s in shards)      # the lockstep-phase leg
-    assert all(s[2]["auto_reset"] == "lazy" for s in shards)                                             # the lazy leg ran too
+    k = 1
+    if scaling == "weak":
+        # world > 1 under weak scaling: the strong-scaling leg splits the configured env count (101) over the ranks
+        assert [s[1]["num_envs"] for s in shards] == [51, 50] and [s[1]["env_id_offset"] for s in shards] == [0, 51]
+        st = d["strong_scaling"]
+        assert st["total_envs"] == 101 and st["envs_per_gpu"] == 51 and st["shard_range_rank0"] == [0, 51] and st["value"] > 0
+        assert abs(st["value"] - 101 * 7 / (st["ms_per_step"] * 7e-3)) < 1e-6 * st["value"] and len(st["env_steps_per_sec"]) == 2
+        k = 2
+    else:
+        assert "strong_scaling" not in d
+    assert all(s[k]["auto_reset"] == "True" and s[k]["num_envs"] == s[0]["num_envs"] for s in shards)      # the lockstep-phase leg
+    assert all(s[k + 1]["auto_reset"] == "lazy" for s in shards)                                         # the lazy leg ran too
     assert d["lockstep_phase"]["steps"] == 20 and d["lockstep_phase"]["value"] > 0
+    ag = d["aged_state"]                                     # the same handle after the untimed pre-roll, same windows
+    assert ag["preroll_steps"] == 25 + 3 + 2 * 7 and ag["value"] > 0 and len(ag["env_steps_per_sec"]) == 2
+    assert ag["step_kernel_ms"] == 0.5 and ag["reset_kernels_ms"] == 0.25
+    rf = d["roofline"]
+    assert rf["bound"] == "valu/latency" and rf["reported_against"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert {"avg_ms", "share", "traffic", "resets_per_call", "algorithmic_bytes_per_launch", "achieved_GBs", "frac"} <= set(rf["kernels"]["reset"])
     assert abs(d["value"] - d["config"]["total_envs"] * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
     assert len(d["repeats"]["env_steps_per_sec"]) == 2 and d["repeats"]["min"] <= d["value"] <= d["repeats"]["max"]
     assert d["roofline"]["kernels"]["reset"]["avg_ms"] == 0.25 and abs(d["roofline"]["kernel_avg_ms"] - 0.75) < 1e-9

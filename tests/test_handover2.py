@@ -282,7 +282,8 @@ def test_gpu_handover2_reset_sampling_and_properties(oracle, gref):
     s = env.get_state().cpu().numpy().astype(np.float64)
     ora.reset()
     so = ora.get_state()
-    assert np.median(np.abs(s[:, CONT] - so[:, CONT]).max(axis=1)) < 2e-4       # six ticks from the same start
+    # six ticks from the same start; the arms swing home at up to 10 rad/s, so the float32 error is relative
+    assert np.median((np.abs(s[:, CONT] - so[:, CONT]) / (1 + np.abs(so[:, CONT]))).max(axis=1)) < 2e-4
     assert (np.abs(s[:, 64:70] - so[:, 64:70]).max(axis=1) < 1e-5).mean() > 0.999   # goals: same attempts up to a tie on a boundary
     assert (np.abs(s[:, 39] - s[:, 42]) >= 0.05 - 1e-3).all()
     acts = [torch.rand(E, 8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(k)) * 2 - 1 for k in range(3)]

@@ -14,7 +14,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="$ROOT/bench.py --workload $WL --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-lazy $*"
+BENCH="$ROOT/bench.py --workload $WL --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-extras $*"
 timeout -k 5 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -- python3 $BENCH > $OUT/stats.log 2>&1
 timeout -k 5 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout -k 5 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python3 $BENCH > $OUT/pmc_write.log 2>&1

@@ -5,9 +5,9 @@
 set -e
 export XARM_BENCH_DEVICE=0 XARM_BENCH_BACKEND=gloo
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
-    bench.py --gpus 2 --steps 10 --warmup 3 --envs-per-gpu 8192 --no-lazy > gpurun_out/bench_2rank_gloo.json 2> gpurun_out/bench_2rank_gloo.err
+    bench.py --gpus 2 --steps 10 --warmup 3 --envs-per-gpu 8192 --no-extras > gpurun_out/bench_2rank_gloo.json 2> gpurun_out/bench_2rank_gloo.err
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29512 \
-    bench.py --gpus 4 --steps 10 --warmup 3 --scaling strong --no-lazy > gpurun_out/bench_4rank_gloo.json 2> gpurun_out/bench_4rank_gloo.err
+    bench.py --gpus 4 --steps 10 --warmup 3 --scaling strong --no-extras > gpurun_out/bench_4rank_gloo.json 2> gpurun_out/bench_4rank_gloo.err
 python - <<'PY'
 import json
 for f in ("gpurun_out/bench_2rank_gloo.json", "gpurun_out/bench_4rank_gloo.json"):

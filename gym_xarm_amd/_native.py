@@ -14,6 +14,7 @@ ENV_STACK_TOWER = 3
 REACH_REWARD_TYPES = {"sparse": 0, "dense": 1, "dense_diff": 2}
 REWARD_TYPES = {"sparse": 0, "dense_o2g": 1, "dense": 2}
 GOAL_SHAPES = {"air": 0, "ground": 1}
+RESET_COOP_LIMIT_DEFAULT = STEP_COOP_LIMIT_DEFAULT = 8192   # include/xarm_hip.h XARM_*_COOP_LIMIT_DEFAULT
 
 EXPORTS = ["xarm_create", "xarm_destroy", "xarm_dims", "xarm_reset", "xarm_step", "xarm_compute_reward",
            "xarm_get_state", "xarm_set_state", "xarm_episode_steps", "xarm_debug_substeps", "xarm_timing_enable", "xarm_timing_read", "xarm_timing_read_reset", "xarm_kernel_limits", "xarm_last_error",
@@ -45,7 +46,9 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # XARM_HIP_LIB: a development variant of the library (tools/coop_split.sh, tools/variant_time.sh) loaded from its own
+    # path; xarm_version() tells a timing variant from the product build.  Still no fallback: a missing file raises.
+    p = path or os.environ.get("XARM_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise XarmNativeError(
             "HIP extension %s not found: build it with `python -m gym_xarm_amd.build` (hipcc, gfx950). "

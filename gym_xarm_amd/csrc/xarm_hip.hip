@@ -971,7 +971,14 @@ static void timing_flush(xarm_handle *h) {
 
 extern "C" {
 
+// a timing variant built with -DXC_SWEEP_ITERS=n (tools/coop_split.sh) runs fewer solver sweeps: it must never pass for the product
+#define XARM_STR2(x) #x
+#define XARM_STR(x) XARM_STR2(x)
+#ifdef XARM_SWEEP_VARIANT
+const char *xarm_version(void) { return "xarm_hip 0.1 (gfx950) TIMING VARIANT sweeps=" XARM_STR(XARM_SWEEP_VARIANT); }
+#else
 const char *xarm_version(void) { return "xarm_hip 0.1 (gfx950)"; }
+#endif
 
 const char *xarm_last_error(const xarm_handle *h) { return h ? h->err : g_err; }
 
@@ -1018,8 +1025,9 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.coop_limit = 0;
     if (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH) {
         h->kp.coop_limit = cfg->reset_coop_limit > 0 ? cfg->reset_coop_limit : (cfg->reset_coop_limit < 0 ? 0 : XARM_RESET_COOP_LIMIT_DEFAULT);
+        // the environment variable replaces the DEFAULT only: an explicit xarm_config value (incl. "< 0 = never") wins
         const char *ev = getenv("XARM_RESET_COOP_LIMIT");
-        if (ev && *ev) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+        if (ev && *ev && cfg->reset_coop_limit == 0) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
     // cooperative step kernel: pays while the one-env-per-lane launch would leave SIMDs empty (measured cross-over,
     // DESIGN.md 5); XARM_STEP_COOP_LIMIT overrides, 0 disables
@@ -1027,7 +1035,8 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
                          (cfg->step_coop_limit > 0 ? cfg->step_coop_limit : XARM_STEP_COOP_LIMIT_DEFAULT);
     {
         const char *ev = getenv("XARM_STEP_COOP_LIMIT");
-        if (ev && *ev && (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH)) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+        if (ev && *ev && cfg->step_coop_limit == 0 && (cfg->env_kind == XARM_ENV_PICK_AND_PLACE || cfg->env_kind == XARM_ENV_REACH))
+            h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
     const bool handover2 = handover && cfg->num_obj == 2;
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover2 ? xh2::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM)));

@@ -18,6 +18,43 @@ def shard_range(total_envs, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def reproducible_limits(total_envs, family=None):
+    """Kernel-family pins (`reset_coop_limit`, `step_coop_limit` of xarm_config / make()) that make a shard's result
+    BITWISE independent of the world size.
+
+    By default a handle picks its kernels from its OWN batch size (include/xarm_hip.h: batches / reset lists of at most
+    8 192 envs run on the cooperative 16-lanes-per-env kernels), so the 8 192-env shard of a 65 536-env job on 8 GPUs
+    steps on k_step_coop while the same envs on one GPU step on k_step - the two agree to float32 rounding, and contact
+    chaos then separates the trajectories.  With these limits passed to EVERY shard (and to the single-GPU run) all of
+    them use one family, chosen from the TOTAL env count:
+      family 'lane' (default when total_envs > 8 192): (-1, -1), the one-env-per-lane kernels everywhere - what a single
+          GPU runs for the step at that size; resets then cost six ticks of a lone wavefront (slow: the price of the pin);
+      family 'coop' (default otherwise): (total_envs, total_envs), the cooperative kernels everywhere.
+    Speed, not semantics, depends on the choice (tests/test_gpu_parity.py::test_world_size_invariance_at_the_baseline_split)."""
+    from ._native import RESET_COOP_LIMIT_DEFAULT
+    if family is None:
+        family = "lane" if int(total_envs) > RESET_COOP_LIMIT_DEFAULT else "coop"
+    if family == "lane":
+        return {"reset_coop_limit": -1, "step_coop_limit": -1}
+    if family == "coop":
+        return {"reset_coop_limit": int(total_envs), "step_coop_limit": int(total_envs)}
+    raise ValueError("family must be 'lane' or 'coop'")
+
+
+def make_shard(env_id, total_envs, rank=None, world_size=None, reproducible=False, **kwargs):
+    """This rank's shard of a `total_envs` job: gym_xarm_amd.make with num_envs / env_id_offset from shard_range.
+    reproducible=True (or 'lane' / 'coop') adds reproducible_limits(total_envs): bitwise the same per-env results at
+    every world size, at the cost of the per-shard kernel choice."""
+    import gym_xarm_amd
+    r, _, w = env_from_torchrun()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    lo, hi = shard_range(total_envs, rank, world_size)
+    if reproducible:
+        kwargs.update(reproducible_limits(total_envs, None if reproducible is True else reproducible))
+    return gym_xarm_amd.make(env_id, num_envs=hi - lo, env_id_offset=lo, **kwargs)
+
+
 def env_from_torchrun():
     """(rank, local_rank, world_size) from the torch.distributed.run environment."""
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

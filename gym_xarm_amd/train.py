@@ -85,9 +85,14 @@ class VecNormalize:
             raise ValueError("VecNormalize statistics are for observation width %d, this env has %d" % (sd["obs_mean"].shape[0], self.dim))
         self.obs_rms.mean, self.obs_rms.var = sd["obs_mean"].to(dev).clone(), sd["obs_var"].to(dev).clone()
         self.obs_rms.count = float(sd["obs_count"])
-        self.ret_rms.mean, self.ret_rms.var = sd["ret_mean"].to(dev).clone(), sd["ret_var"].to(dev).clone()
-        self.ret_rms.count = float(sd["ret_count"])
-        self.clip_obs, self.clip_reward, self.gamma = float(sd["clip_obs"]), float(sd["clip_reward"]), float(sd["gamma"])
+        # files written before the return statistics / clip settings were saved (round 1's --save) hold the observation
+        # statistics only: keep this wrapper's own values for what the file lacks
+        if "ret_mean" in sd:
+            self.ret_rms.mean, self.ret_rms.var = sd["ret_mean"].to(dev).clone(), sd["ret_var"].to(dev).clone()
+            self.ret_rms.count = float(sd["ret_count"])
+        self.clip_obs = float(sd["clip_obs"]) if "clip_obs" in sd else self.clip_obs
+        self.clip_reward = float(sd["clip_reward"]) if "clip_reward" in sd else self.clip_reward
+        self.gamma = float(sd["gamma"]) if "gamma" in sd else self.gamma
 
     def save(self, path):
         """counterpart of `env.save(stats_path)` (benchmark/train.py:107-108): the running statistics and the clip /
@@ -187,7 +192,10 @@ class SaveOnBestTrainingRewardCallback:
         if self.n_calls % self.check_freq:
             return True
         self.monitor.flush()
-        mean_reward = self.monitor.mean_reward(100)
+        # the reference's Monitor sees sequential episodes of 4 envs and averages the last 100 (benchmark/train.py:30-33);
+        # with thousands of envs finishing in the same call the last 100 entries are one corner of one batch, so the window
+        # is widened to at least one episode per env
+        mean_reward = self.monitor.mean_reward(max(100, int(self.monitor.ep_ret.numel())))
         if mean_reward is None:
             return True
         if self.verbose > 0:

@@ -138,8 +138,8 @@ int xarm_timing_read(xarm_handle *h, double *step_kernel_ms_total, int64_t *laun
 /* same for the reset kernels that follow the step kernel inside xarm_step (auto_reset): total ms over `launches` calls */
 int xarm_timing_read_reset(xarm_handle *h, double *reset_kernels_ms_total, int64_t *launches);
 
-/* the limits in force for this handle after defaults and the XARM_RESET_COOP_LIMIT / XARM_STEP_COOP_LIMIT environment
- * overrides: batches / reset lists of at most that many envs run on the cooperative kernels (0: never) */
+/* the limits in force for this handle.  Precedence: an explicit xarm_config value (> 0, or < 0 = never) wins; with the
+ * field at 0 the XARM_RESET_COOP_LIMIT / XARM_STEP_COOP_LIMIT environment variable replaces the built-in default: batches / reset lists of at most that many envs run on the cooperative kernels (0: never) */
 int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit);
 
 const char *xarm_last_error(const xarm_handle *h);

@@ -274,6 +274,56 @@ def test_full_size_properties_16384(gx):
     assert int((ep == 2).sum()) >= 4 * E // 50 - 8             # four calls x E / 50 time-limit resets (+ successes)
 
 
+def test_world_size_invariance_at_the_baseline_split(gx):
+    """'1-GPU vs 8-GPU bitwise-equal per env' at BASELINE's own split - 65 536 envs on one handle against the
+    8 192-env shard [k 8192, (k + 1) 8192) a rank of an 8-GPU job owns.  By default the shard would step on the cooperative
+    kernels and the full batch on the one-env-per-lane kernel (equal to float32 rounding only); with the kernel family
+    pinned from the TOTAL env count (gym_xarm_amd.distributed.reproducible_limits) the results are
+    bitwise equal - in either family."""
+    from gym_xarm_amd import distributed as D
+    E, n, k = 65536, 8192, 5
+    off = k * n
+    a = [torch.rand(E, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(40 + j)) * 2 - 1 for j in range(3)]
+    assert D.reproducible_limits(E) == {"reset_coop_limit": -1, "step_coop_limit": -1}
+    assert D.reproducible_limits(4096) == {"reset_coop_limit": 4096, "step_coop_limit": 4096}
+
+    def run(num, offset, limits):
+        env = gx.make("XarmPDPickAndPlace-v0", num_envs=num, seed=29, env_id_offset=offset, **limits)
+        lim = env.kernel_limits()
+        env.reset()
+        env.set_episode_steps((torch.arange(num, device="cuda") + offset) * 7919 % 50)    # time-limit resets in every call
+        for j in range(3):
+            obs, rew, done, info = env.step(a[j][offset:offset + num])
+        out = env.get_state().clone(), obs["observation"].clone(), rew.clone(), done.clone()
+        env.close()
+        return out, lim
+    for family in ("lane", "coop"):
+        limits = D.reproducible_limits(E, family)
+        full, lim_full = run(E, 0, limits)
+        shard, lim_shard = run(n, off, limits)
+        assert lim_full == lim_shard == ((0, 0) if family == "lane" else (E, E))
+        for x, y in zip(full, shard):
+            assert torch.equal(x[off:off + n], y), family                      # bitwise, per env
+        assert int((full[0][:, 53] >= 2).sum()) >= 3 * E // 50 - 8             # resets really ran inside the step calls
+    # the default (per-shard) choice: same envs, different kernel family -> float32-close, not bitwise
+    dflt, lim = run(n, off, {})
+    assert lim == (8192, 8192)
+    err = (dflt[0][:, :18] - full[0][off:off + n, :18]).abs().max(dim=1).values
+    assert float(err.median()) < 1e-4 and bool(torch.equal(dflt[0][:, 31:34], full[0][off:off + n, 31:34]))
+
+
+def test_env_override_applies_to_the_default_limits_only(gx, monkeypatch):
+    """XARM_RESET_COOP_LIMIT / XARM_STEP_COOP_LIMIT replace the built-in DEFAULT; an explicit xarm_config value - incl.
+    '< 0 = never' - wins (include/xarm_hip.h xarm_kernel_limits)"""
+    monkeypatch.setenv("XARM_RESET_COOP_LIMIT", "1024")
+    monkeypatch.setenv("XARM_STEP_COOP_LIMIT", "2048")
+    for kw, want in (({}, (1024, 2048)), ({"reset_coop_limit": -1, "step_coop_limit": -1}, (0, 0)),
+                     ({"reset_coop_limit": 512, "step_coop_limit": 256}, (512, 256))):
+        env = gx.make("XarmPDPickAndPlace-v0", num_envs=64, seed=1, **kw)
+        assert env.kernel_limits() == want, (kw, env.kernel_limits())
+        env.close()
+
+
 def test_dense_reward_on_grasp_rollout(gxk, oracle, golden_rollout, parity):
     """reward_type='dense' (:166-175): staged reward incl. the contact-flag branches, HIP vs oracle"""
     g = golden_rollout

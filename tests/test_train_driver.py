@@ -143,3 +143,29 @@ def test_train_loop_writes_monitor_checkpoint_and_stats(tmp_path):
     assert venv.callback.n_calls == 60 and venv.monitor.n > 100 and len(hist) == 2
     rows = open(os.path.join(str(tmp_path), "0.monitor.csv")).read().strip().split("\n")
     assert len(rows) - 2 == venv.monitor.n
+
+
+def test_vecnormalize_loads_statistics_files_without_the_later_keys():
+    """files written before the return statistics / clip settings were saved hold obs_* only: load keeps the wrapper's own
+    values for what the file lacks instead of raising KeyError"""
+    env = ScriptedEnv(4)
+    a, b = VecNormalize(env, clip_obs=7.0, gamma=0.9), VecNormalize(env, clip_obs=3.0, gamma=0.5)
+    a.reset()
+    for _ in range(5):
+        a.step(torch.zeros(4, 2))
+    sd = {k: v for k, v in a.state_dict().items() if k.startswith("obs_")}
+    b.load_state_dict(sd)
+    assert torch.equal(b.obs_rms.mean, a.obs_rms.mean) and b.clip_obs == 3.0 and b.gamma == 0.5
+    b.load_state_dict(a.state_dict())
+    assert b.clip_obs == 7.0 and abs(b.gamma - 0.9) < 1e-6 and torch.equal(b.ret_rms.var, a.ret_rms.var)      # gamma travels as float32
+
+
+def test_best_model_window_covers_every_env():
+    """with thousands of envs finishing in one call the reference's 'last 100 episodes' (benchmark/train.py:30-33) would be
+    one corner of one batch: the callback averages over at least one episode per env"""
+    E = 300
+    mon = EpisodeMonitor(E, torch.device("cpu"))
+    rew = torch.arange(E, dtype=torch.float32)
+    mon.update(rew, torch.ones(E, dtype=torch.uint8))      # all E envs finish in the same call
+    assert abs(mon.mean_reward(100) - float(rew[-100:].mean())) < 1e-4      # the biased corner
+    assert abs(mon.mean_reward(max(100, E)) - float(rew.mean())) < 1e-4

@@ -48,6 +48,11 @@ register("XarmReach-v0", "gym_xarm_amd.envs:XarmReachEnv", 25, "gym_xarm_amd.vec
 # gym_xarm/__init__.py:12-16 and its README / BASELINE.json alias
 for _id in ("XarmHandover-v0", "XarmPDHandover-v0"):
     register(_id, "gym_xarm_amd.envs:XarmHandover", 100, "gym_xarm_amd.vec_env:XarmHandoverVecEnv")
+# the flat-observation id the reference trains on (benchmark/train.py:67, plot.py:5; README.md:38 spells it
+# XarmPDHandoverDenseEnvNoGoal-v1): unregistered in the reference itself; observation 29 (what its saved vec_normalize.pkl
+# documents), staged dense reward (train.py:66)
+for _id in ("XarmPDHandoverNoGoal-v1", "XarmPDHandoverDenseEnvNoGoal-v1"):
+    register(_id, "gym_xarm_amd.sb3_adapter:XarmHandoverNoGoal", 100, "gym_xarm_amd.sb3_adapter:make_handover_nogoal_vec")
 # not in the reference's registry (the class exists, xarm_stack_tower.py:13, _max_episode_steps = 50 :43); BASELINE.json
 # config 4 names it XarmPDStackTower-v0
 for _id in ("XarmStackTower-v0", "XarmPDStackTower-v0"):

@@ -38,13 +38,17 @@ class VecNormalize:
     def __init__(self, env, clip_obs=10.0, clip_reward=10.0, gamma=0.99, eps=1e-8):
         self.env, self.clip_obs, self.clip_reward, self.gamma, self.eps = env, clip_obs, clip_reward, gamma, eps
         dev = env.device
-        self.dim = env.obs_dim + 2 * env.goal_dim
+        # a flat-observation ('NoGoal') env hands out the observation tensor itself (gym_xarm_amd/sb3_adapter.py FlatObsVecEnv)
+        self.flat = bool(getattr(env, "flat_observation", False))
+        self.dim = env.obs_dim if self.flat else env.obs_dim + 2 * env.goal_dim
         self.obs_rms = RunningMeanStd((self.dim,), dev)
         self.ret_rms = RunningMeanStd((), dev)
         self.ret = torch.zeros(env.num_envs, device=dev)
         self.training = True
 
     def _flat(self, obs):
+        if self.flat:
+            return obs
         return torch.cat([obs["observation"], obs["achieved_goal"], obs["desired_goal"]], dim=1)
 
     def _norm(self, x, keep=None):
@@ -326,6 +330,8 @@ def main():
     ap.add_argument("--check-freq", type=int, default=1000)
     args = ap.parse_args()
     cfg = {"reward_type": args.reward_type, "GUI": False} if ("Reach" in args.env or "PickAndPlace" in args.env) else None
+    if "Handover" in args.env and "NoGoal" not in args.env:
+        cfg = {"reward_type": args.reward_type}
     model, venv, hist = train(args.env, args.num_envs, args.updates, config=cfg, auto_reset="lazy" if args.lazy_reset else True,
                               log_dir=args.log_dir, check_freq=args.check_freq)
     if args.save:

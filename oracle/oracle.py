@@ -176,6 +176,7 @@ def lib():
         L.xo_pnp_reset.argtypes = [mp, cp, C.c_int64, dp, u8p, dp, dp, dp]
         L.xo_pnp_step.argtypes = [mp, cp, C.c_int64, dp, dp, dp, dp, dp, dp, u8p, u8p]
         L.xo_pnp_compute_reward.argtypes = [mp, _i, C.c_int64, dp, dp, dp]
+        L.xo_pnp_substeps.argtypes = [mp, C.c_int64, dp, dp, C.c_int32]
         L.xo_pnp_dense_reward.argtypes = [mp, _i, dp, dp, dp]
         L.xo_pnp_dense_reward.restype = _d
         hp = C.POINTER(XoHoCfg)
@@ -254,6 +255,11 @@ class OraclePnP:
         rt = self.cfg.reward_type if reward_type is None else REWARD_TYPES[reward_type]
         self.L.xo_pnp_compute_reward(self.m, rt, ag.shape[0], _p(ag), _p(g), _p(out))
         return out
+
+    def debug_substeps(self, q_target, n):
+        """n internal substeps toward joint targets [E, 9] (counterpart of the C ABI's xarm_debug_substeps)"""
+        qt = np.ascontiguousarray(q_target, dtype=np.float64).reshape(self.E, 9)
+        self.L.xo_pnp_substeps(self.m, self.E, _p(self.state), _p(qt), int(n))
 
     def get_state(self):
         return self.state.copy()
@@ -513,3 +519,36 @@ def philox(seed, c0, c1, c2, c3):
     out = (C.c_uint32 * 4)()
     lib().xo_philox(seed, c0, c1, c2, c3, out)
     return [int(x) for x in out]
+
+
+def run_demo(env, get_state, set_state, substeps, n_sub=15):
+    """Literal replay of XarmPickAndPlace._run_demo (xarm_pick_and_place.py:310-349), the reference's only grasp sequence,
+    on `env` (the oracle or the HIP env through the callables): after reset() the object is teleported to [0.4, 0, 0.025]
+    (:312), then 10 ticks with the arm motors on IK([0.4, 0, 0.125]) (:314-318), 3 ticks with the finger motors on 0.02 and
+    the friction toggled from the finger contacts (:322-330; the arm motors keep their last targets), 10 ticks with the arm
+    on IK([0.3, 0, 0.3]) and the same toggle (:336-346).  IK runs every tick from the current pose (maxNumIterations = 15)
+    - here through the oracle's xo_ik for both users, the step-level tests cover the device's own IK.  The demo's finger
+    motors are left at the default force; the model's finger force (1000, :210-211) is used.  During the first 10 ticks
+    the finger motors still hold the reset's 0.02 target (:256-257).  Returns the states after each of the 23 ticks."""
+    st = np.array(get_state(), dtype=np.float64)
+    E = st.shape[0]
+    st[:, 18:21] = [0.4, 0.0, 0.025]
+    st[:, 21:25] = [0, 0, 0, 1]
+    st[:, 25:31] = 0
+    st[:, 34:50] = 0
+    set_state(st)
+    out = []
+    qt = st[:, :9].copy()
+    for phase, n_ticks, target in ((0, 10, (0.4, 0.0, 0.125)), (1, 3, None), (2, 10, (0.3, 0.0, 0.3))):
+        for _ in range(n_ticks):
+            st = np.array(get_state(), dtype=np.float64)
+            if target is not None:
+                for e in range(E):
+                    qt[e, :7] = ik(st[e, :9], target)[:7]
+            qt[:, 7:9] = 0.02
+            if phase >= 1:
+                st[:, 51] = st[:, 50]          # lateralFriction 100 / 1 from the current finger contacts (:325-330, :340-345)
+                set_state(st)
+            substeps(qt, n_sub)
+            out.append(np.array(get_state(), dtype=np.float64))
+    return np.stack(out)

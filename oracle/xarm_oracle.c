@@ -978,6 +978,15 @@ int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *sta
     return 0;
 }
 
+/* test hook, counterpart of xarm_debug_substeps: n internal substeps (dt = time_step / n_substeps) toward the joint
+ * targets q_target [E, 9]; no action / IK / observation logic.  Used for the literal replay of
+ * XarmPickAndPlace._run_demo (xarm_pick_and_place.py:310-349), which drives the motors below env.step. */
+int xo_pnp_substeps(const xo_model *m, int64_t E, double *state, const double *q_target, int32_t n) {
+    real dt = m->time_step / m->n_substeps;
+    for (int64_t e = 0; e < E; e++)
+        for (int k = 0; k < n; k++) substep(m, state + e * XO_STATE_DIM, q_target + e * 9, dt);
+    return 0;
+}
 int xo_fk(const xo_model *m, const double *q, double *link_pos, double *link_rot) {
     tree_t t;
     tree_setup(m, q, &t);

@@ -95,6 +95,8 @@ int xo_pnp_reset(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *st
 int xo_pnp_step(const xo_model *m, const xo_pnp_cfg *cfg, int64_t E, double *state,
                 const double *actions, double *obs, double *ag, double *dg, double *reward,
                 uint8_t *done, uint8_t *success);
+/* test hook (counterpart of xarm_debug_substeps): n internal substeps toward the joint targets q_target [E, 9] */
+int xo_pnp_substeps(const xo_model *m, int64_t E, double *state, const double *q_target, int32_t n);
 /* batched reward restatement: xarm_pick_and_place.py:155-177 (sparse, dense_o2g) */
 int xo_pnp_compute_reward(const xo_model *m, int reward_type, int64_t n, const double *ag,
                           const double *g, double *out);

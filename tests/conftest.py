@@ -252,6 +252,36 @@ class HostCore:
         return out
 
 
+class OracleTorchEnv:
+    """the CPU oracle behind the torch VecEnv call surface the scripted policies use (reset / step / get_state over CPU
+    tensors, auto_reset off) - lets gym_xarm_amd/policies.py run unchanged on the oracle and on the HIP env"""
+
+    def __init__(self, ora):
+        import torch
+        self.torch, self.ora, self.num_envs, self.device = torch, ora, ora.E, torch.device("cpu")
+
+    def _obs(self, o):
+        t = self.torch
+        return {"observation": t.tensor(o[0], dtype=t.float32), "achieved_goal": t.tensor(o[1], dtype=t.float32),
+                "desired_goal": t.tensor(o[2], dtype=t.float32)}
+
+    def reset(self):
+        return self._obs(self.ora.reset())
+
+    def step(self, a):
+        t = self.torch
+        o = self.ora.step(a.double().numpy())
+        return self._obs(o), t.tensor(o[3], dtype=t.float32), t.tensor(o[4]), {"is_success": t.tensor(o[5])}
+
+    def get_state(self):
+        return self.torch.tensor(self.ora.get_state(), dtype=self.torch.float32)
+
+
+@pytest.fixture(scope="session")
+def oracle_torch_env():
+    return OracleTorchEnv
+
+
 @pytest.fixture(scope="session")
 def hostcore():
     return HostCore()

@@ -347,6 +347,23 @@ def test_dense_reward_on_grasp_rollout(gxk, oracle, golden_rollout, parity):
     env.close()
 
 
+def test_run_demo_literal_replay(gx, oracle):
+    """XarmPickAndPlace._run_demo (xarm_pick_and_place.py:310-349) replayed tick by tick through the C ABI
+    (xarm_debug_substeps / get_state / set_state) next to the oracle's replay: same grasp, same lift"""
+    E = 16
+    ora = oracle.OraclePnP(E, seed=4)
+    ora.reset()
+    So = oracle.run_demo(ora, ora.get_state, ora.set_state, ora.debug_substeps)
+    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=4, auto_reset=False)
+    env.reset()
+    Sd = oracle.run_demo(env, lambda: _np(env.get_state()), lambda s: env.set_state(torch.tensor(s, dtype=torch.float32)),
+                         lambda qt, n: env.debug_substeps(torch.tensor(qt, dtype=torch.float32), n))
+    assert (Sd[-1, :, 20] > 0.2).all() and (Sd[-1, :, 50] == 1).all() and (Sd[10:13, :, 50] == 1).all()
+    np.testing.assert_allclose(Sd[-1, :, 18:21], So[-1, :, 18:21], atol=5e-3)       # 23 free-running ticks, float32 vs float64
+    np.testing.assert_allclose(Sd[-1, :, :7], So[-1, :, :7], atol=5e-3)
+    env.close()
+
+
 def test_auto_reset_matches_oracle_step_then_reset(gxk, oracle):
     """auto-reset path (k_step -> done list -> k_reset) against oracle.step followed by oracle.reset(mask)"""
     E = 128
@@ -380,11 +397,13 @@ def test_auto_reset_matches_oracle_step_then_reset(gxk, oracle):
 def test_scripted_pick_and_lift_rate(gxk, tmp_path):
     """behavioural regression (cf. the reference's _run_demo :310-349): the closed-loop scripted policy lifts
     most objects that do not start under the gripper; also snapshot / restore of the simulator state"""
-    from gym_xarm_amd.policies import lift_rate, PickAndLiftPolicy
+    from gym_xarm_amd.policies import lift_stages
     E = 2048
     env = gxk.make("XarmPDPickAndPlace-v0", num_envs=E, seed=5, auto_reset=False)
-    rate = lift_rate(env)
-    assert rate > 0.4, rate   # objects spawned under the gripper (~25 %) are thrown off the table by the reset
+    st = lift_stages(env)
+    # oracle, 192 envs: hovered 0.92, contact 0.94, raised 0.91, lifted 0.91 (tests/test_policies.py); objects spawned under
+    # the gripper are batted off the table by the reset's own arm motion
+    assert st["hovered"] > 0.8 and st["contact"] > 0.8 and st["lifted"] > 0.8 and st["lifted"] > 0.93 * st["contact"], st
     snap = str(tmp_path / "state.safetensors")
     env.save_state(snap)
     before = env.get_state().clone()

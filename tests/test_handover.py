@@ -272,14 +272,19 @@ def test_gpu_handover_16384_properties_and_registry(gref):
 
 @pytest.mark.gpu
 def test_gpu_scripted_handover_rate():
-    """behavioural regression: the reference's ezpolicy, run on the GPU env, hands a good share of the sticks that
-    start on arm 1's side over to arm 2 (lifted, held by arm 2 alone)"""
+    """behavioural regression with the per-stage breakdown (tests/test_policies.py holds the oracle's): the reference's
+    ezpolicy on the GPU env gets the stick reached, grasped and lifted by arm 1 in (nearly) every env and both fingers of
+    arm 2 onto it in most; it never commands a release, so arm 2 ends up alone with the stick only when it tears it free;
+    with the release step added (HandoverReleasePolicy) the hand-over completes several times as often"""
     import gym_xarm_amd as gx
-    from gym_xarm_amd.policies import handover_rate
+    from gym_xarm_amd.policies import handover_stages, HandoverReleasePolicy
     env = gx.make("XarmPDHandover-v0", num_envs=2048, seed=11, auto_reset=False)
-    rate = handover_rate(env, steps=40)
+    st = handover_stages(env, steps=40)
+    assert st["reached"] > 0.97 and st["grasp1"] > 0.97 and st["lifted"] > 0.95, st
+    assert st["contact2"] > 0.4 and 0.03 < st["handed"] < 0.3, st
+    rel = handover_stages(env, 60, HandoverReleasePolicy(env))
     env.close()
-    assert rate > 0.06, rate     # ~0.12-0.13 measured; the reference controller is crude (no alignment of the grasp)
+    assert rel["handed"] > 2 * st["handed"] and rel["held_end"] > 0.15, (st, rel)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,203 @@
+"""gym_xarm_amd/sb3_adapter.py: the Stable-Baselines3-shaped surface benchmark/train.py:74-79 drives.
+
+stable_baselines3 is not importable here (and must not be fetched), so the adapter is checked against the documented
+VecEnv contract with a stub consumer that behaves like a rollout buffer - it STORES the arrays it is handed and reads them
+after further steps.  CPU tests run the adapter over a torch stand-in that, like the real VecEnv, hands out the same
+buffers every call; the GPU tests run it over the HIP envs.  PARITY UNPINNED for this surface (never run against SB3)."""
+import numpy as np
+import pytest
+import torch
+
+from gym_xarm_amd.sb3_adapter import SB3VecEnv, VecExtractDictObs, FlatObsVecEnv
+from gym_xarm_amd.spaces import Box, Dict
+
+
+class AliasingEnv:
+    """torch VecEnv stand-in: persistent buffers overwritten in place (gym_xarm_amd/vec_env.py does the same), episode length
+    3 + (e % 3), auto-reset with terminal_observation, goal = 100 * episode + e"""
+    AG_SLICE = slice(0, 3)
+
+    def __init__(self, E):
+        self.num_envs, self.obs_dim, self.goal_dim, self.act_dim = E, 5, 3, 2
+        self.device = torch.device("cpu")
+        self.action_space = Box(-1.0, 1.0, shape=(2,), dtype=np.float32)
+        self.observation_space = Dict(dict(desired_goal=Box(-np.inf, np.inf, shape=(3,), dtype=np.float32),
+                                           achieved_goal=Box(-np.inf, np.inf, shape=(3,), dtype=np.float32),
+                                           observation=Box(-np.inf, np.inf, shape=(5,), dtype=np.float32)))
+        self._obs, self._ag, self._dg = torch.zeros(E, 5), torch.zeros(E, 3), torch.zeros(E, 3)
+        self._rew, self._done, self._succ, self._term = torch.zeros(E), torch.zeros(E, dtype=torch.uint8), torch.zeros(E, dtype=torch.uint8), torch.zeros(E, 5)
+        self.t, self.ep = torch.zeros(E), torch.zeros(E)
+        self.length = 3 + torch.arange(E) % 3
+        self.distance_threshold = 0.05
+        self._max_episode_steps = 5
+
+    def _fill(self):
+        e = torch.arange(self.num_envs, dtype=torch.float32)
+        self._obs[:] = torch.stack([self.t * 10 + e + k for k in range(5)], dim=1)
+        self._ag[:] = self._obs[:, :3]
+        self._dg[:] = (100 * self.ep + e)[:, None]
+
+    def reset(self, mask=None):
+        self.t.zero_()
+        self._fill()
+        return {"observation": self._obs, "achieved_goal": self._ag, "desired_goal": self._dg}
+
+    def step(self, a):
+        assert torch.is_tensor(a) and a.shape == (self.num_envs, 2)
+        self.t += 1
+        self._fill()
+        self._rew[:] = a[:, 0] + self.t
+        done = self.t >= self.length
+        self._done[:] = done.to(torch.uint8)
+        self._succ[:] = (done & (torch.arange(self.num_envs) % 2 == 0)).to(torch.uint8)
+        self._term[done] = self._obs[done]
+        self.ep += done.float()
+        self.t[done] = 0
+        self._fill()
+        info = {"is_success": self._succ, "terminal_observation": self._term, "TimeLimit.truncated": (self._done != 0) & (self._succ == 0)}
+        return {"observation": self._obs, "achieved_goal": self._ag, "desired_goal": self._dg}, self._rew, self._done, info
+
+    def compute_reward(self, ag, g, info=None):
+        return -((ag - g).norm(dim=-1) > self.distance_threshold).float()
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def close(self):
+        self.closed = True
+
+
+def test_adapter_contract_with_a_consumer_that_keeps_references():
+    E = 6
+    raw = AliasingEnv(E)
+    env = SB3VecEnv(raw)
+    assert env.num_envs == E and env.action_space.shape == (2,)
+    kept = []                                       # what a rollout buffer does: keep what it was given
+    obs = env.reset()
+    assert isinstance(obs, dict) and obs["observation"].dtype == np.float32 and obs["observation"].shape == (E, 5)
+    kept.append((obs, None, None, None, {k: v.copy() for k, v in obs.items()}))
+    rng = np.random.default_rng(0)
+    n_term = 0
+    for t in range(9):
+        a = rng.uniform(-1, 1, (E, 2)).astype(np.float32)
+        env.step_async(a)
+        obs, rew, done, infos = env.step_wait()
+        assert isinstance(rew, np.ndarray) and rew.dtype == np.float32 and rew.shape == (E,)
+        assert done.dtype == bool and done.shape == (E,)
+        assert isinstance(infos, list) and len(infos) == E and all(isinstance(d, dict) for d in infos)
+        for i in range(E):
+            assert ("terminal_observation" in infos[i]) == bool(done[i]) == ("TimeLimit.truncated" in infos[i])
+            assert infos[i]["is_success"] in (0.0, 1.0)
+            if done[i]:
+                n_term += 1
+                to = infos[i]["terminal_observation"]
+                assert set(to) == {"observation", "achieved_goal", "desired_goal"}
+                # the last observation of the finished episode, with ITS goal (not the next episode's)
+                ep_len = 3 + i % 3
+                assert to["observation"][0] == ep_len * 10 + i and np.array_equal(to["achieved_goal"], to["observation"][:3])
+                assert to["desired_goal"][0] == 100 * (raw.ep[i].item() - 1) + i
+                assert infos[i]["TimeLimit.truncated"] == (i % 2 == 1) and infos[i]["is_success"] == float(i % 2 == 0)
+                assert obs["observation"][i, 0] == i                     # row i already holds the next episode's first observation
+                assert obs["desired_goal"][i, 0] == 100 * raw.ep[i].item() + i
+        kept.append((obs, rew, done, infos, {k: v.copy() for k, v in obs.items()}))
+    assert n_term >= 8
+    # nothing that was handed out has changed since (the torch env underneath overwrote its buffers nine times)
+    for obs, rew, done, infos, snap in kept:
+        for k in snap:
+            assert np.array_equal(obs[k], snap[k])
+    rews = [k[1] for k in kept[1:]]
+    assert len({id(r) for r in rews}) == len(rews) and not np.array_equal(rews[0], rews[1])
+    # VecEnv utility surface
+    out = env.env_method("compute_reward", np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32), [{}] * 4, indices=[0])
+    assert len(out) == 1 and out[0].shape == (4,) and (out[0] == -1).all()
+    assert env.env_method("compute_reward", np.zeros(3, np.float32), np.zeros(3, np.float32), {})[0] == 0.0
+    assert env.get_attr("distance_threshold") == [0.05] * E and env.get_attr("_max_episode_steps", indices=[1, 2]) == [5, 5]
+    env.set_attr("distance_threshold", 0.1)
+    assert raw.distance_threshold == 0.1
+    assert env.env_is_wrapped(object) == [False] * E and env.seed(3) == [3 + i for i in range(E)]
+    with pytest.raises(AssertionError, match="action shape"):
+        env.step_async(np.zeros((E, 3), np.float32))
+    env.close()
+    assert raw.closed
+
+
+def test_vec_extract_dict_obs_matches_the_references_wrapper():
+    """benchmark/train.py:49-63: observation_space = the key's space, reset / step_wait return obs[key]"""
+    env = VecExtractDictObs(SB3VecEnv(AliasingEnv(4)), "observation")
+    assert env.observation_space.shape == (5,) and env.num_envs == 4
+    o = env.reset()
+    assert isinstance(o, np.ndarray) and o.shape == (4, 5)
+    seen = False
+    for t in range(5):
+        env.step_async(np.zeros((4, 2), np.float32))
+        o, r, d, infos = env.step_wait()
+        assert o.shape == (4, 5)
+        for i in np.nonzero(d)[0]:
+            assert infos[i]["terminal_observation"].shape == (5,)      # flat, like the observation space
+            seen = True
+    assert seen and env.get_attr("distance_threshold") == [0.05] * 4      # falls through to the wrapped env
+
+
+def test_flat_obs_view_and_the_nogoal_registry_entry():
+    import gym_xarm_amd
+    for env_id in ("XarmPDHandoverNoGoal-v1", "XarmPDHandoverDenseEnvNoGoal-v1"):      # benchmark/train.py:67, README.md:38
+        assert env_id in gym_xarm_amd.registered_ids() and gym_xarm_amd.spec(env_id)["max_episode_steps"] == 100
+    flat = FlatObsVecEnv(AliasingEnv(3))
+    assert flat.flat_observation and flat.observation_space.shape == (5,) and flat.goal_dim == 0
+    o = flat.reset()
+    assert torch.is_tensor(o) and o.shape == (3, 5)
+    o, r, d, info = flat.step(torch.zeros(3, 2))
+    assert o.shape == (3, 5) and "is_success" in info
+    from gym_xarm_amd.train import VecNormalize
+    vn = VecNormalize(flat)
+    assert vn.dim == 5 and vn.reset().shape == (3, 5)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_adapter_over_the_hip_env_and_nogoal_ids():
+    from gym_xarm_amd.sb3_adapter import make_vec_env
+    env = make_vec_env("XarmPDPickAndPlace-v0", n_envs=64, seed=0)
+    obs = env.reset()
+    first = {k: v.copy() for k, v in obs.items()}
+    kept, n_done = [obs], 0
+    rng = np.random.default_rng(0)
+    for t in range(55):
+        o, r, d, infos = env.step(rng.uniform(-1, 1, (64, 4)).astype(np.float32))
+        kept.append(o)
+        for i in np.nonzero(d)[0]:
+            n_done += 1
+            to = infos[i]["terminal_observation"]
+            assert to["observation"].shape == (24,) and np.array_equal(to["achieved_goal"], to["observation"][8:11])
+            assert np.array_equal(to["desired_goal"], kept[-2]["desired_goal"][i])       # the finished episode's goal
+            assert infos[i]["TimeLimit.truncated"] == (infos[i]["is_success"] == 0.0)
+    assert n_done >= 64                                       # every env hit the 50-step limit at least once
+    for k in first:
+        assert np.array_equal(kept[0][k], first[k])           # the first arrays were never overwritten
+    rr = env.env_method("compute_reward", kept[-1]["achieved_goal"], kept[-1]["desired_goal"], [{}] * 64, indices=[0])[0]
+    assert rr.shape == (64,) and set(np.unique(rr)) <= {0.0, 1.0}
+    env.close()
+    ng = make_vec_env("XarmPDHandoverNoGoal-v1", n_envs=32, seed=1)          # benchmark/train.py:67,74
+    o = ng.reset()
+    assert o.shape == (32, 29) and ng.observation_space.shape == (29,)
+    o, r, d, infos = ng.step(np.zeros((32, 8), np.float32))
+    assert o.shape == (32, 29) and r.shape == (32,) and (r > 0).all() and (r < 1).all()     # staged dense reward in (0, 1)
+    ng.close()
+    import gym_xarm_amd
+    one = gym_xarm_amd.make("XarmPDHandoverNoGoal-v1")
+    ob = one.reset()
+    assert ob.shape == (29,) and one.observation_space.contains(ob)
+    ob, r, d, info = one.step(one.action_space.sample())
+    assert ob.shape == (29,) and 0.0 < r < 1.0
+    one.close()
+
+
+@pytest.mark.gpu
+def test_gpu_a2c_on_handover_dense_nogoal_learns():
+    """the reference's training setting (benchmark/train.py:66-79: reward_type 'dense', XarmPDHandoverNoGoal-v1,
+    VecNormalize, A2C MlpPolicy) on the on-device driver: the mean staged reward rises"""
+    from gym_xarm_amd.train import train
+    model, venv, hist = train("XarmPDHandoverNoGoal-v1", num_envs=2048, updates=240, log_every=40, quiet=True, seed=0)
+    assert venv.dim == 29
+    first, last = hist[0]["mean_raw_reward"], max(h["mean_raw_reward"] for h in hist[-2:])
+    assert last > first * 1.15 and last > first + 0.004, hist

@@ -197,7 +197,10 @@ def test_gpu_a2c_on_handover_dense_nogoal_learns():
     """the reference's training setting (benchmark/train.py:66-79: reward_type 'dense', XarmPDHandoverNoGoal-v1,
     VecNormalize, A2C MlpPolicy) on the on-device driver: the mean staged reward rises"""
     from gym_xarm_amd.train import train
-    model, venv, hist = train("XarmPDHandoverNoGoal-v1", num_envs=2048, updates=240, log_every=40, quiet=True, seed=0)
+    # measured on one MI355X (tools/learn_probe.py, gpurun_out/r03b/learn2.log): mean staged reward per step 0.12 (random:
+    # the reach stage tops out at 0.111) -> 0.26 / 0.34 / 0.41 after 150 / 300 / 450 / 600 updates at lr 2e-3, gamma 0.95;
+    # SB3's A2C defaults (lr 7e-4, gamma 0.99) reach 0.63 (arm 1 grasps and lifts, arm 2 joins) after 3 000 updates, 67 s
+    model, venv, hist = train("XarmPDHandoverNoGoal-v1", num_envs=2048, updates=600, log_every=150, lr=2e-3, gamma=0.95, quiet=True, seed=0)
     assert venv.dim == 29
-    first, last = hist[0]["mean_raw_reward"], max(h["mean_raw_reward"] for h in hist[-2:])
-    assert last > first * 1.15 and last > first + 0.004, hist
+    first, last = hist[0]["mean_raw_reward"], hist[-1]["mean_raw_reward"]
+    assert first < 0.2 and last > 2 * first and last > 0.3, hist      # past the reach stage: the policy grasps (0.22) and lifts (0.44+)

@@ -1,5 +1,7 @@
-import json, sys
+import json, sys, time
 sys.path.insert(0, '/root/repo')
 from gym_xarm_amd.train import train
-model, venv, hist = train("XarmPDHandoverNoGoal-v1", num_envs=2048, updates=240, log_every=40, quiet=True, seed=0)
-print(json.dumps([round(h["mean_raw_reward"], 5) for h in hist]), [h["env_steps_per_sec"] for h in hist][-1])
+for kw in (dict(num_envs=2048, updates=3000, log_every=250), dict(num_envs=4096, updates=1500, log_every=150, n_steps=16), dict(num_envs=2048, updates=1500, log_every=150, lr=2e-3, gamma=0.95)):
+    t = time.time()
+    model, venv, hist = train("XarmPDHandoverNoGoal-v1", quiet=True, seed=0, **kw)
+    print(kw, json.dumps([round(h["mean_raw_reward"], 4) for h in hist]), "succ", [round(h["success_rate"], 3) for h in hist][-3:], "%.0fs" % (time.time() - t), flush=True)

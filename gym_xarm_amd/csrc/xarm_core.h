@@ -106,6 +106,15 @@ XARM_HD Pk<float> pkfma(const Pk<float> &m, float s, const Pk<float> &c) {
 }
 #endif
 template <typename T> XARM_HD T clampT(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// The solver's clamps (lo <= hi always holds there).  On the device one v_med3_f32 / v_max_f32 each: written as comparisons
+// they compile to two v_cmp + two v_cndmask, ~75 of the ~960 instructions of a k_step sweep.  Same value for finite input
+// (the sign of a zero result may differ); the host build and float64 keep the comparisons.
+template <typename T> XARM_HD T sclamp(T v, T lo, T hi) { return clampT(v, lo, hi); }
+template <typename T> XARM_HD T smax0(T v) { return v < (T)0 ? (T)0 : v; }
+#if defined(__HIPCC__) && !defined(XARM_HOST_BUILD)
+XARM_HD float sclamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+XARM_HD float smax0(float v) { return __builtin_fmaxf(v, 0.0f); }
+#endif
 template <typename T> XARM_HD T comp(V3<T> v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 XARM_HD float xsqrt(float x) { return sqrtf(x); }
@@ -954,20 +963,20 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             V3<T> u = vb + cross(wb, P.r);
             T dl = (P.vt - u.z) * lds[LDS_TBL + s * 8 + 5];
             T nl = P.lam[0] + dl;
-            nl = nl < (T)0 ? (T)0 : nl;
+            nl = smax0(nl);
             dl = nl - P.lam[0];
             P.lam[0] = nl;
             V3<T> fi = mk<T>((T)0, (T)0, dl);
             u = u + mk<T>(Kxz, Kyz, Kzz) * dl;
             const T lim = mu_t * P.lam[0];
             dl = u.y * lds[LDS_TBL + s * 8 + 6]; // t1 = -y: jv = -u.y, target 0
-            nl = clampT(P.lam[1] + dl, -lim, lim);
+            nl = sclamp(P.lam[1] + dl, -lim, lim);
             dl = nl - P.lam[1];
             P.lam[1] = nl;
             fi.y = -dl;
             u = u - mk<T>(Kxy, Kyy, Kyz) * dl;
             dl = -u.x * lds[LDS_TBL + s * 8 + 7]; // t2 = +x
-            nl = clampT(P.lam[2] + dl, -lim, lim);
+            nl = sclamp(P.lam[2] + dl, -lim, lim);
             dl = nl - P.lam[2];
             P.lam[2] = nl;
             fi.x = dl;
@@ -979,7 +988,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         for (int i = 0; i < 9; i++) {
             const T hi = i < 7 ? m_hi_arm : m_hi_fin;
             T dl = (m_vt[i] - XARM_DQ(i)) * m_invd[i];
-            const T nl = clampT(m_lam[i] + dl, -hi, hi);
+            const T nl = sclamp(m_lam[i] + dl, -hi, hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
             XARM_DQ_AXPY(i, dl);
@@ -991,7 +1000,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;
-            nl = nl < (T)0 ? (T)0 : nl;
+            nl = smax0(nl);
             dl = (nl - la_lam[i]) * sg;
             la_lam[i] = nl;
             XARM_DQ_AXPY(i, dl);
@@ -1003,7 +1012,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 const T sg = side == 0 ? (T)1 : (T)-1;
                 T dl = (lf_vt[k][side] - sg * XARM_DQ(7 + k)) * m_invd[7 + k];
                 T nl = lf_lam[k][side] + dl;
-                nl = nl < (T)0 ? (T)0 : nl;
+                nl = smax0(nl);
                 dl = (nl - lf_lam[k][side]) * sg;
                 lf_lam[k][side] = nl;
                 XARM_DQ_AXPY(7 + k, dl);
@@ -1011,7 +1020,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         // (G) gear row, q7' - q8' = 0
         {
             T dl = (g_vt - (XARM_DQ(7) - dq8)) * g_invd;
-            const T nl = clampT(g_lam + dl, -g_hi, g_hi);
+            const T nl = sclamp(g_lam + dl, -g_hi, g_hi);
             dl = nl - g_lam;
             g_lam = nl;
             XARM_DQ_AXPY(7, dl);
@@ -1057,20 +1066,20 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                                       K21[fk][6] * f1.x + K21[fk][7] * f1.y + K21[fk][8] * f1.z);
                     T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
                     T nl = P.lam[0] + dl;
-                    nl = nl < (T)0 ? (T)0 : nl;
+                    nl = smax0(nl);
                     dl = nl - P.lam[0];
                     P.lam[0] = nl;
                     V3<T> fi = P.n * dl;
                     u = u + P.Kn * dl;
                     const T lim = mu_p * P.lam[0];
                     dl = -dot(P.t1, u) * e1;
-                    nl = clampT(P.lam[1] + dl, -lim, lim);
+                    nl = sclamp(P.lam[1] + dl, -lim, lim);
                     dl = nl - P.lam[1];
                     P.lam[1] = nl;
                     fi = fi + P.t1 * dl;
                     u = u + P.Kt1 * dl;
                     dl = -dot(t2, u) * e2;
-                    nl = clampT(P.lam[2] + dl, -lim, lim);
+                    nl = sclamp(P.lam[2] + dl, -lim, lim);
                     dl = nl - P.lam[2];
                     P.lam[2] = nl;
                     fi = fi + t2 * dl;

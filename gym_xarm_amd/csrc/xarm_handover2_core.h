@@ -416,18 +416,18 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
                 V3<T> u = vb[o] + cross(wb[o], r);
                 T dl = (lds[base + 6] - u.z) * lds[base + 12];
                 T nl = l0 + dl;
-                nl = nl < (T)0 ? (T)0 : nl;
+                nl = xk::smax0(nl);
                 dl = nl - l0; l0 = nl;
                 V3<T> fi = mk<T>((T)0, (T)0, dl);
                 u = u + mk<T>(Kxz, Kyz, Kzz) * dl;
                 const T lim = mu_t * l0;
                 dl = u.y * lds[base + 13];        // t1 = -y: jv = -u.y, target 0
-                nl = clampT(l1 + dl, -lim, lim);
+                nl = xk::sclamp(l1 + dl, -lim, lim);
                 dl = nl - l1; l1 = nl;
                 fi.y = -dl;
                 u = u - mk<T>(Kxy, Kyy, Kyz) * dl;
                 dl = -u.x * lds[base + 14];       // t2 = +x
-                nl = clampT(l2 + dl, -lim, lim);
+                nl = xk::sclamp(l2 + dl, -lim, lim);
                 dl = nl - l2; l2 = nl;
                 fi.x = dl;
                 vb[o] = vb[o] + fi * imb;
@@ -441,7 +441,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
         for (int i = 0; i < 9; i++) {
             const T hi = i < 7 ? m_hi_arm : m_hi_fin;
             T dl = (m_vt[i] - XARM_DQ(i)) * m_invd[i];
-            const T nl = clampT(m_lam[i] + dl, -hi, hi);
+            const T nl = xk::sclamp(m_lam[i] + dl, -hi, hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
             XARM_DQ_AXPY(i, dl);
@@ -453,7 +453,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
             const T sg = la_sg[i];
             T dl = (la_vt[i] - sg * XARM_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = la_lam[i] + dl;
-            nl = nl < (T)0 ? (T)0 : nl;
+            nl = xk::smax0(nl);
             dl = (nl - la_lam[i]) * sg;
             la_lam[i] = nl;
             XARM_DQ_AXPY(i, dl);
@@ -465,7 +465,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
                 const T sg = side == 0 ? (T)1 : (T)-1;
                 T dl = (lf_vt[k][side] - sg * XARM_DQ(7 + k)) * m_invd[7 + k];
                 T nl = lf_lam[k][side] + dl;
-                nl = nl < (T)0 ? (T)0 : nl;
+                nl = xk::smax0(nl);
                 dl = (nl - lf_lam[k][side]) * sg;
                 lf_lam[k][side] = nl;
                 XARM_DQ_AXPY(7 + k, dl);
@@ -473,7 +473,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
         // (G) gear row
         {
             T dl = (g_vt - (XARM_DQ(7) - dq8)) * g_invd;
-            const T nl = clampT(g_lam + dl, -g_hi, g_hi);
+            const T nl = xk::sclamp(g_lam + dl, -g_hi, g_hi);
             dl = nl - g_lam;
             g_lam = nl;
             XARM_DQ_AXPY(7, dl);
@@ -500,7 +500,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
                     const V3<T> Kd = mk<T>(lds[pb + 13 + 3 * k], lds[pb + 14 + 3 * k], lds[pb + 15 + 3 * k]);
                     T dl = ((k == 0 ? vt : (T)0) - dot(d, u)) * ed[k];
                     const T lim = mu_bb * lam[0];
-                    const T nl = k == 0 ? (lam[0] + dl < (T)0 ? (T)0 : lam[0] + dl) : clampT(lam[k] + dl, -lim, lim);
+                    const T nl = k == 0 ? xk::smax0(lam[0] + dl) : xk::sclamp(lam[k] + dl, -lim, lim);
                     dl = nl - lam[k];
                     lam[k] = nl;
                     u = u + Kd * dl;
@@ -542,20 +542,20 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
                     V3<T> u = mk<T>(y[3], y[4], y[5]) + cross(mk<T>(y[0], y[1], y[2]), P.p) + af * yf[fk] - vc - cross(wc, r);
                     T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
                     T nl = P.lam[0] + dl;
-                    nl = nl < (T)0 ? (T)0 : nl;
+                    nl = xk::smax0(nl);
                     dl = nl - P.lam[0];
                     P.lam[0] = nl;
                     V3<T> fi = P.n * dl;
                     u = u + P.Kn * dl;
                     const T lim = mu_p * P.lam[0];
                     dl = -dot(P.t1, u) * e1;
-                    nl = clampT(P.lam[1] + dl, -lim, lim);
+                    nl = xk::sclamp(P.lam[1] + dl, -lim, lim);
                     dl = nl - P.lam[1];
                     P.lam[1] = nl;
                     fi = fi + P.t1 * dl;
                     u = u + P.Kt1 * dl;
                     dl = -dot(t2, u) * e2;
-                    nl = clampT(P.lam[2] + dl, -lim, lim);
+                    nl = xk::sclamp(P.lam[2] + dl, -lim, lim);
                     dl = nl - P.lam[2];
                     P.lam[2] = nl;
                     fi = fi + t2 * dl;

@@ -251,7 +251,7 @@ template <typename T> XARM_HD void substep(EnvState<T> &st, const T dt) {
 #pragma unroll
         for (int i = 0; i < ND; i++) {
             T dl = (m_vt[i] - XR_DQ(i)) * m_invd[i];
-            const T nl = clampT(m_lam[i] + dl, -m_hi, m_hi);
+            const T nl = xk::sclamp(m_lam[i] + dl, -m_hi, m_hi);
             dl = nl - m_lam[i];
             m_lam[i] = nl;
             XR_DQ_AXPY(i, dl);
@@ -262,7 +262,7 @@ template <typename T> XARM_HD void substep(EnvState<T> &st, const T dt) {
             const T sg = l_sg[i];
             T dl = (l_vt[i] - sg * XR_DQ(i)) * (sg != (T)0 ? m_invd[i] : (T)0);
             T nl = l_lam[i] + dl;
-            nl = nl < (T)0 ? (T)0 : nl;
+            nl = xk::smax0(nl);
             dl = (nl - l_lam[i]) * sg;
             l_lam[i] = nl;
             XR_DQ_AXPY(i, dl);

@@ -1032,7 +1032,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         for (int ph = 0; ph < Scene::NARMS; ph++) {
         // two arms: sequential (phase = arm) when both touch the object; otherwise the touching arm sweeps in phase 0
         const bool mine = Scene::NARMS == 1 || (seq ? arm == ph : ph == 0);
-        if (XARM_ANY(pad_any && mine)) {
+        if (XARM_ANY(pad_any && mine)) {   // NOT a rare path at wave level: ~2 % of the envs hold a finger contact, i.e. 1 - 0.98^64 = 73 % of the wavefronts (a __builtin_expect(.., 0) here took k_step from 2.02 to 3.15 ms)
             T y[6], yf[2], wtot[8];
 #pragma unroll
             for (int k = 0; k < 6; k++) {

@@ -383,7 +383,8 @@ template <typename T> struct ArmDyn {
     V3<T> fo[2];       // finger frame origins
 };
 // OPSPACE = false (cooperative core, xarm_coop_core.h): only S is staged, T and A_hh are not formed.
-template <typename T, typename Lds, typename Scene, bool OPSPACE = true>
+// STAGE_S = false (the pad-free fast step, substep<.., FAST>): nothing of the arm goes to LDS at all.
+template <typename T, typename Lds, typename Scene, bool OPSPACE = true, bool STAGE_S = true>
 XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, const int arm, ArmDyn<T> &A) {
     // ---------------- kinematics + world-frame RNEA / CRBA
     SV<T> S[7];      // joint motion axes about the world origin
@@ -573,7 +574,7 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
 #pragma unroll
             for (int k = 0; k < 6; k++) lds[LDS_T + r * 6 + k] = Tm[r][k];
         XARM_LDS_FENCE();
-    } else {
+    } else if (STAGE_S) {
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             lds[LDS_S + i * 6 + 0] = S[i].w.x; lds[LDS_S + i * 6 + 1] = S[i].w.y; lds[LDS_S + i * 6 + 2] = S[i].w.z;
@@ -590,11 +591,20 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
 // Dual-arm scenes run one arm per lane: `arm` selects the base frame, `xchg.from(a, v)` returns the copy of v
 // held by the lane of arm a of the same environment (object velocities are handed over between the two
 // finger/object phases of a sweep; everything else is either per-arm or computed identically by both lanes).
-template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg>
-XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
+//
+// FAST = true: the same substep with every finger-pad ROW compiled out - no operational-space blocks, no pad warm start,
+// no F phase, nothing of the arm staged in LDS.  It is exact (bit for bit the sweep below: an inactive pad carries
+// 1/diag = 0 and contributes nothing) for as long as no pad of the environment is within the solver margin of the object,
+// and it says so: the return value is "a pad row of this environment is active in this substep".  The fast step kernel
+// runs it on every environment and hands the ones that answer true to a kernel that solves pad rows (xarm_hip.hip,
+// k_step_fast): ~2 % of the environments hold a finger contact, but that is >= 1 lane in most wavefronts, and a wavefront
+// with one such lane sweeps the pad blocks for all 64 (k_step 1.88 ms against 0.74 ms for a contact-free batch).
+template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg, bool FAST = false>
+XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
+    static_assert(!FAST || Scene::NARMS == 1, "the pad-free fast substep exists for the single-arm scene");
     const T idt = (T)1 / dt;
     ArmDyn<T> AD;
-    arm_dynamics<T, Lds, Scene>(st.q, st.qd, dt, lds, arm, AD);
+    arm_dynamics<T, Lds, Scene, !FAST, !FAST>(st.q, st.qd, dt, lds, arm, AD);
     T (&Minv)[45] = AD.Minv;
     T (&dq)[9] = AD.dq;
     const V3<T> hc0 = AD.hc0, hc1 = AD.hc1, hc2 = AD.hc2;
@@ -822,7 +832,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
             P.lam[1] = P.lam[2] = (T)0;
             P.invd[0] = P.invd[1] = P.invd[2] = (T)0;
             P.Kn = P.Kt1 = P.Kt2 = mk<T>(0, 0, 0);
-            if (XARM_ANY(act)) {
+            if (!FAST && XARM_ANY(act)) {
                 // 3x3 point Delassus block K = K_A (arm side, through A) + K_B (object side)
                 const V3<T> af = hc1 * sg;
                 const V3<T> r = P.p - cb;
@@ -868,7 +878,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 wb = wb - symmul(Iinv, cross(r, fi));
             }
         }
-        if (XARM_ANY(pad_any)) {
+        if (!FAST && XARM_ANY(pad_any)) {
 #pragma unroll
             for (int r = 0; r < 9; r++) {
                 T s = Minv[symi(r, 7)] * wtot[6] + Minv[symi(r, 8)] * wtot[7];
@@ -1032,7 +1042,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
         for (int ph = 0; ph < Scene::NARMS; ph++) {
         // two arms: sequential (phase = arm) when both touch the object; otherwise the touching arm sweeps in phase 0
         const bool mine = Scene::NARMS == 1 || (seq ? arm == ph : ph == 0);
-        if (XARM_ANY(pad_any && mine)) {   // NOT a rare path at wave level: ~2 % of the envs hold a finger contact, i.e. 1 - 0.98^64 = 73 % of the wavefronts (a __builtin_expect(.., 0) here took k_step from 2.02 to 3.15 ms)
+        if (!FAST && XARM_ANY(pad_any && mine)) {   // NOT a rare path at wave level: ~2 % of the envs hold a finger contact, i.e. 1 - 0.98^64 = 73 % of the wavefronts (a __builtin_expect(.., 0) here took k_step from 2.02 to 3.15 ms)
             T y[6], yf[2], wtot[8];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -1151,7 +1161,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 #pragma unroll
         for (int s = 0; s < NTS; s++) l = tp[s].id == i ? tp[s].lam[0] : l;
         st.lam_t[i] = l;
-        st.lam_p[i] = i < NP ? pp[i < NP ? i : 0].lam[0] : (T)0;
+        st.lam_p[i] = (!FAST && i < NP) ? pp[i < NP ? i : 0].lam[0] : (T)0;
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) { st.qd[i] = dq[i]; st.q[i] += dt * dq[i]; }
@@ -1175,6 +1185,7 @@ XARM_HD void substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     st.bv[0] = vb.x; st.bv[1] = vb.y; st.bv[2] = vb.z;
     st.bw[0] = wb.x; st.bw[1] = wb.y; st.bw[2] = wb.z;
     (void)mb;
+    return pad_any;
 }
 
 // p.stepSimulation() with numSubSteps = 15
@@ -1318,6 +1329,40 @@ XARM_HD void env_step(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (
     success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
     reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
     done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
+}
+
+// XarmPickAndPlace.step on the pad-free fast substep.  Returns false when a finger-pad row of this environment was
+// active in any of the 15 substeps: the outputs are then meaningless and the caller must not store them (the
+// environment is stepped again, from its untouched state, by a kernel that solves pad rows).
+template <typename T, typename Lds>
+XARM_HD bool env_step_fast(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (&obs)[OBS_DIM], T &reward, bool &done,
+                           bool &success, Lds lds) {
+    st.steps += (T)1;
+    T a[4], qt[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = clampT(act[k], (T)-1, (T)1);
+    Frame<T> f = frame_identity<T>();
+#pragma unroll
+    for (int i = 0; i < 7; i++) fk_advance(f, i, st.q[i]);
+    const T sc = (T)(xm::PNP_MAX_VEL * xm::PNP_ACTION_DT);
+    const V3<T> target = mk<T>(clampT(f.o.x + a[0] * sc, (T)xm::PNP_POS_LOW[0], (T)xm::PNP_POS_HIGH[0]),
+                               clampT(f.o.y + a[1] * sc, (T)xm::PNP_POS_LOW[1], (T)xm::PNP_POS_HIGH[1]),
+                               clampT(f.o.z + a[2] * sc, (T)xm::PNP_POS_LOW[2], (T)xm::PNP_POS_HIGH[2]));
+    const T g = clampT(st.q[7] + a[3] * (T)(xm::PNP_ACTION_DT * xm::PNP_MAX_GRIPPER_VEL), (T)xm::PNP_GRIPPER_LOW, (T)xm::PNP_GRIPPER_HIGH);
+    ik_solve(st.q, target, qt);
+    qt[7] = qt[8] = g;
+    st.mug = st.touch;
+    const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+    bool pad = false;
+#pragma unroll 1
+    for (int k = 0; k < xm::PNP_N_SUBSTEPS; k++) pad = substep<T, Lds, PnpScene, NoXchg, true>(st, qt, dt, lds) || pad;
+    get_obs(st, obs);
+    const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
+    const T dist = xsqrt(dx * dx + dy * dy + dz * dz);
+    success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
+    reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
+    done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
+    return !pad;
 }
 
 // Lazy auto-reset (opt-in, NOT the reference's VecEnv semantics): instead of running the reference's

@@ -85,11 +85,20 @@ typedef struct xarm_config {
                                (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
     int32_t step_coop_limit;  /* PickAndPlace, Reach: a handle of at most this many envs also STEPS on the cooperative kernel
                                  (the one-env-per-lane launch would leave most SIMDs without a wavefront);
-                                 0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never */
+                                 0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never.  Larger PickAndPlace handles step on
+                                 the pad-free fast kernel and hand the envs with an active finger-pad row to the cooperative
+                                 kernel (XARM_EJECT_COOP_CAP); < 0 also pins those to the plain one-env-per-lane k_step */
     int32_t use_stand;        /* XarmHandover config['use_stand'] (xarm_handover.py:391-392): a static 0.07 x 0.06 x 0.01 box
                                  whose top sits 25 mm under the goal; 0 = parked away (the BASELINE configuration) */
 } xarm_config;                /* 72 bytes */
 #define XARM_RESET_COOP_LIMIT_DEFAULT 8192
+/* PickAndPlace batches above step_coop_limit step on the pad-free fast kernel; the envs with an active finger-pad row
+ * (~2 % in the steady state, ~16 % in the first steps after a bulk reset) are handed off to the cooperative kernel -
+ * hand-offs of more than this many envs to the one-env-per-lane kernel.  The break-even is ~8 192 envs; the cap is set
+ * well above it (the first steps after a bulk reset of 65 536 envs hand off ~17 000) so that the choice - which, like the
+ * reset family, depends on a COUNT and therefore on the shard - is only ever crossed by configurations that start most
+ * episodes in the gripper (init_grasp_rate) */
+#define XARM_EJECT_COOP_CAP 32768
 /* PickAndPlace handles of at most this many envs step on the cooperative kernel as well (env XARM_STEP_COOP_LIMIT) */
 #define XARM_STEP_COOP_LIMIT_DEFAULT 8192
 

@@ -81,6 +81,17 @@ class HostCore:
                        self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ))
         return st, obs, ag, dg, rew, done, succ
 
+    def step_fast(self, state, actions, f32=1, **kw):
+        """xk::env_step_fast: the pad-free fast step; ok[e] = 0 -> a finger-pad row was active, row e is returned untouched"""
+        E = state.shape[0]
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 24)), np.zeros((E, 3)), np.zeros((E, 3))
+        rew, done, succ, ok = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+        self.L.xh_step_fast(C.c_int(f32), *self._cfg(**kw), C.c_int64(E), self._p(st), self._p(a), self._p(obs),
+                            self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ), self._u8(ok))
+        return st, obs, ag, dg, rew, done, succ, ok.astype(bool)
+
     def coop_step(self, state, actions, f32=1, **kw):
         """xc::env_step: the 16-lanes-per-env impulse-space core (csrc/xarm_coop_core.h)"""
         E = state.shape[0]

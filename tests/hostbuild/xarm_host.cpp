@@ -54,6 +54,21 @@ void do_step(const xk::EnvCfg &cfg, int64_t E, double *state, const double *act,
         rew[e] = r; done[e] = d; succ[e] = su;
     }
 }
+// the pad-free fast step (xk::env_step_fast): ok[e] = 0 when a finger-pad row was active (outputs meaningless, state untouched)
+template <typename T> void do_step_fast(const xk::EnvCfg &c, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, uint8_t *ok) {
+    for (int64_t e = 0; e < E; e++) {
+        xk::EnvState<T> s; load(state + e * xk::STATE_DIM, s);
+        T lds[xk::LDS_FLOATS]; HostLds<T> hl{lds};
+        T a[4], o[xk::OBS_DIM], r; bool d, su;
+        for (int k = 0; k < 4; k++) a[k] = (T)act[e * 4 + k];
+        ok[e] = xk::env_step_fast<T>(c, s, a, o, r, d, su, hl) ? 1 : 0;
+        if (!ok[e]) continue;
+        store(s, state + e * xk::STATE_DIM);
+        for (int k = 0; k < xk::OBS_DIM; k++) obs[e * xk::OBS_DIM + k] = o[k];
+        for (int k = 0; k < 3; k++) { ag[e * 3 + k] = s.bp[k]; dg[e * 3 + k] = s.goal[k]; }
+        rew[e] = r; done[e] = d; succ[e] = su;
+    }
+}
 template <typename T>
 void do_step_lazy(const xk::EnvCfg &cfg, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
     for (int64_t e = 0; e < E; e++) {
@@ -351,6 +366,10 @@ void xh_step(int f32, CFGARGS, int64_t E, double *state, const double *act, doub
 void xh_reset(int f32, CFGARGS, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
     auto c = mkcfg(seed, off, igr, ggr, gs, rt);
     if (f32) do_reset<float>(c, E, state, mask, obs, ag, dg); else do_reset<double>(c, E, state, mask, obs, ag, dg);
+}
+void xh_step_fast(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, uint8_t *ok) {
+    auto c = mkcfg(seed, off, igr, ggr, gs, rt);
+    if (f32) do_step_fast<float>(c, E, state, act, obs, ag, dg, rew, done, succ, ok); else do_step_fast<double>(c, E, state, act, obs, ag, dg, rew, done, succ, ok);
 }
 void xh_coop_step(int f32, CFGARGS, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ) {
     auto c = mkcfg(seed, off, igr, ggr, gs, rt);

@@ -25,8 +25,9 @@ def _np(t):
 
 class _Maker:
     """gx.make with the PickAndPlace kernel family pinned: 'lane' = one env per lane for step and reset (k_step /
-    k_reset, what a 65 536-env batch steps on), 'coop' = the 16-lanes-per-env kernels (k_step_coop / k_reset_coop,
-    the default for the batch sizes of these tests)"""
+    k_reset), 'coop' = the 16-lanes-per-env kernels (k_step_coop / k_reset_coop, the default for the batch sizes of
+    these tests), 'fast' = what a 65 536-env batch steps on by default: the pad-free fast kernel with the hand-off of the
+    envs that have an active finger-pad row to the cooperative kernel (k_step_fast + k_step_coop_list), resets on k_reset"""
 
     def __init__(self, gx, family):
         self.gx, self.family, self.vec_env = gx, family, gx.vec_env
@@ -35,10 +36,13 @@ class _Maker:
         if self.family == "lane":
             kw.setdefault("step_coop_limit", -1)
             kw.setdefault("reset_coop_limit", -1)
+        if self.family == "fast":
+            kw.setdefault("step_coop_limit", 1)       # every batch of more than one env is "large": the fast pipeline
+            kw.setdefault("reset_coop_limit", -1)
         return self.gx.make(env_id, **kw)
 
 
-@pytest.fixture(scope="module", params=["lane", "coop"])
+@pytest.fixture(scope="module", params=["lane", "coop", "fast"])
 def gxk(request, gx):
     return _Maker(gx, request.param)
 
@@ -310,6 +314,41 @@ def test_world_size_invariance_at_the_baseline_split(gx):
     assert lim == (8192, 8192)
     err = (dflt[0][:, :18] - full[0][off:off + n, :18]).abs().max(dim=1).values
     assert float(err.median()) < 1e-4 and bool(torch.equal(dflt[0][:, 31:34], full[0][off:off + n, 31:34]))
+
+
+def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
+    """What a large PickAndPlace batch steps on by default - k_step_fast (the pad-free substep) with the hand-off of the
+    envs that have an active finger-pad row to k_step_coop_list - against the plain k_step: an env that is never handed
+    off is the same BITS (the fast substep is the plain one minus blocks that are no-ops for it), a handed-off env agrees
+    to float32 rounding (it is stepped by the cooperative core); XARM_STEP_PIPELINE=0 and step_coop_limit < 0 select the
+    plain kernel"""
+    E = 8192
+    a = [torch.rand(E, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(70 + j)) * 2 - 1 for j in range(4)]
+
+    def run(**kw):
+        env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=31, auto_reset=False, reset_coop_limit=-1, **kw)
+        env.reset()
+        sts = []
+        for j in range(4):
+            env.step(a[j])
+            sts.append(env.get_state().clone())
+        env.close()
+        return sts
+    fast, plain = run(step_coop_limit=1), run(step_coop_limit=-1)
+    same = torch.ones(E, dtype=torch.bool, device="cuda")
+    for j in range(4):
+        # pad rows in play at some point of step j: an impulse at its end, or the contact flag
+        pad = (plain[j][:, 42:46] != 0).any(dim=1) | (plain[j][:, 50] != 0)
+        same &= ~pad
+        eq = (fast[j] == plain[j]).all(dim=1)
+        assert bool(eq[same].all()), (j, int((~eq[same]).sum()))                     # never in contact so far: bit for bit
+        err = (fast[j][:, :31] - plain[j][:, :31]).abs().max(dim=1).values
+        assert float(err.median()) == 0.0 and float(err[~same].median()) < 1e-3, j  # handed off: float32 rounding, then contact chaos
+    assert 0.5 < float(same.float().mean()) < 0.99                                    # both populations are well represented
+    monkeypatch.setenv("XARM_STEP_PIPELINE", "0")
+    off = run(step_coop_limit=1)
+    for x, y in zip(off, plain):
+        assert torch.equal(x, y)                                                      # the override selects the plain kernel
 
 
 def test_env_override_applies_to_the_default_limits_only(gx, monkeypatch):

@@ -9,7 +9,7 @@ other = [0, 0.0]
 for r in rows:
     n = r["Name"]
     short = None
-    m = __import__("re").search(r"::(k_[a-z_]+)\(", n)
+    m = __import__("re").search(r"::(k_[a-z_0-9]+)[<(]", n)      # template kernels: k_ho_step<xh::HandoverScene>(...)
     if m:
         short = m.group(1)
     if short is None:

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-STEP_KERNEL = {"pnp": "k_step", "reach": "k_reach_step", "handover": "k_ho_step", "stack": "k_st_step"}
+STEP_KERNEL = {"pnp": "k_step_fast", "reach": "k_reach_step", "handover": "k_ho_step", "stack": "k_st_step"}
 RESET_KERNEL = {"pnp": "k_reset_coop", "reach": "k_reach_reset", "handover": "k_ho_reset", "stack": "k_st_reset"}
 
 
@@ -22,6 +22,8 @@ def main():
     t = json.load(open(out)) if os.path.exists(out) else (json.load(open(base)) if os.path.exists(base) else {})
     for role, names in (("step", STEP_KERNEL), ("reset", RESET_KERNEL)):
         k = names[wl]
+        if k == "k_step_fast" and k not in d:    # plain kernel (pipeline off) or the cooperative family
+            k = "k_step"
         if k not in d and k + "_coop" in d:      # the cooperative family served this batch size (pnp, reach)
             k = k + "_coop"
         if k not in d or "FETCH_SIZE" not in d[k] or "WRITE_SIZE" not in d[k]:

@@ -101,3 +101,26 @@ def test_dense_reward_f64_matches_oracle(oracle, hostcore, golden_rollout):
         st, obs, ag, dg, rew, done, succ = hostcore.step(S[t], A[t], f32=0, seed=1, rt=2)
         ok = g["grasp_sens"][t] < 1e-2
         np.testing.assert_allclose(rew[ok], o[3][ok], atol=1e-9)
+
+
+def test_fast_step_is_the_plain_step_for_every_env_it_accepts(hostcore, golden_rollout):
+    """xk::env_step_fast (the pad-free substep behind k_step_fast): on every env it accepts the result is the plain
+    env_step's bit for bit - state, observation, reward, done - in float32 and in float64; an env it rejects (a finger-pad
+    row became active) comes back untouched; and no env that ends the step with a pad impulse is ever accepted"""
+    g = golden_rollout
+    for key in ("rand", "grasp"):
+        S, A = g[key + "_states"], g[key + "_actions"]
+        n_ok = n_all = 0
+        for t in range(0, A.shape[0], 2):
+            for f32 in (0, 1):
+                a = hostcore.step(S[t], A[t], f32=f32)
+                b = hostcore.step_fast(S[t], A[t], f32=f32)
+                ok = b[7]
+                assert np.array_equal(b[0][ok], a[0][ok]) and np.array_equal(b[1][ok], a[1][ok])
+                assert np.array_equal(b[4][ok], a[4][ok]) and np.array_equal(b[5][ok], a[5][ok]) and np.array_equal(b[6][ok], a[6][ok])
+                assert np.array_equal(b[0][~ok], S[t][~ok])
+                pad = (a[0][:, 42:46] != 0).any(axis=1)
+                assert not (pad & ok).any()
+            n_ok += ok.sum()
+            n_all += ok.size
+        assert (0.85 < n_ok / n_all <= 1.0) if key == "rand" else (0.4 < n_ok / n_all < 0.9)   # the grasp script lives in contact

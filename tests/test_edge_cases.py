@@ -58,3 +58,26 @@ def test_an_env_does_not_depend_on_its_batch(env_id, A):
         ref = got if ref is None else ref
         assert torch.equal(got, ref[:E]), "envs differ at batch size %d" % E
         env.close()
+
+
+def test_fast_pipeline_at_ragged_sizes():
+    """k_step_fast + the hand-off (what large PickAndPlace batches step on) at env counts that leave a ragged last
+    workgroup in the fast kernel and a ragged last row group in the hand-off kernel, with auto-reset on: every env equals,
+    bit for bit, the same global env id in a larger batch of the same pipeline - whichever wavefront its hand-off shares"""
+    import torch
+    import gym_xarm_amd
+    ref = None
+    for E in (1000, 1, 63, 65, 37 * 4 + 3, 999):
+        env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=5, step_coop_limit=1, reset_coop_limit=0)
+        assert env.kernel_limits()[1] == 1
+        env.reset()
+        env.set_episode_steps(torch.arange(E, device=env.device) % 50)        # time-limit resets inside the step calls
+        gen = torch.Generator(device=env.device)
+        gen.manual_seed(1)
+        for _ in range(4):
+            a = torch.rand(1000, 4, device=env.device, generator=gen)[:E] * 2 - 1
+            obs, rew, done, info = env.step(a)
+        got = torch.cat([obs["observation"], obs["achieved_goal"], obs["desired_goal"], rew[:, None], env.get_state()], dim=1).clone()
+        ref = got if ref is None else ref
+        assert torch.isfinite(got).all() and torch.equal(got, ref[:E]), "envs differ at batch size %d" % E
+        env.close()

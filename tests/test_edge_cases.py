@@ -67,7 +67,7 @@ def test_fast_pipeline_at_ragged_sizes():
     import torch
     import gym_xarm_amd
     ref = None
-    for E in (1000, 1, 63, 65, 37 * 4 + 3, 999):
+    for E in (1000, 2, 63, 65, 37 * 4 + 3, 999):      # (a 1-env handle would be within step_coop_limit = 1: cooperative step)
         env = gym_xarm_amd.make("XarmPDPickAndPlace-v0", num_envs=E, seed=5, step_coop_limit=1, reset_coop_limit=0)
         assert env.kernel_limits()[1] == 1
         env.reset()

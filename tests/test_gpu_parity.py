@@ -327,26 +327,33 @@ def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
 
     def run(**kw):
         env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=31, auto_reset=False, reset_coop_limit=-1, **kw)
-        env.reset()
-        sts = []
+        o = env.reset()["observation"]
+        sts, dist = [], [(o[:, 0:3] - o[:, 8:11]).norm(dim=1).clone()]       # hand COM to object centre
         for j in range(4):
-            env.step(a[j])
+            o = env.step(a[j])[0]["observation"]
             sts.append(env.get_state().clone())
+            dist.append((o[:, 0:3] - o[:, 8:11]).norm(dim=1).clone())
         env.close()
-        return sts
-    fast, plain = run(step_coop_limit=1), run(step_coop_limit=-1)
-    same = torch.ones(E, dtype=torch.bool, device="cuda")
+        return sts, dist
+    (fast, _), (plain, dist) = run(step_coop_limit=1), run(step_coop_limit=-1)
+    far = torch.ones(E, dtype=torch.bool, device="cuda")
+    n_eq = 0
     for j in range(4):
-        # pad rows in play at some point of step j: an impulse at its end, or the contact flag
-        pad = (plain[j][:, 42:46] != 0).any(dim=1) | (plain[j][:, 50] != 0)
-        same &= ~pad
+        # the hand COM travels < 7 cm per step and the pads sit < 13 cm from it: an env whose object was more than 30 cm
+        # from the hand before and after every step so far never had a pad inside the 5 mm solver margin, so it was never
+        # handed off - it must be the same bits.  (That every env with a pad impulse IS handed off, and that the fast step
+        # equals the plain one on every env it accepts, is checked exactly on the host: tests/test_hostcore.py.)
+        far &= (dist[j] > 0.30) & (dist[j + 1] > 0.30)
         eq = (fast[j] == plain[j]).all(dim=1)
-        assert bool(eq[same].all()), (j, int((~eq[same]).sum()))                     # never in contact so far: bit for bit
+        n_eq += int(eq.sum())
+        assert bool(eq[far].all()), (j, int((~eq[far]).sum()))
         err = (fast[j][:, :31] - plain[j][:, :31]).abs().max(dim=1).values
-        assert float(err.median()) == 0.0 and float(err[~same].median()) < 1e-3, j  # handed off: float32 rounding, then contact chaos
-    assert 0.5 < float(same.float().mean()) < 0.99                                    # both populations are well represented
+        assert float(err.median()) == 0.0, j                               # most envs are never handed off
+        if bool((~eq).any()):
+            assert float(err[~eq].median()) < 1e-3, j                      # handed off: float32 rounding, then contact chaos
+    assert int(far.sum()) > 200 and 0.5 * 4 * E < n_eq < 0.995 * 4 * E     # both populations are well represented
     monkeypatch.setenv("XARM_STEP_PIPELINE", "0")
-    off = run(step_coop_limit=1)
+    off, _ = run(step_coop_limit=1)
     for x, y in zip(off, plain):
         assert torch.equal(x, y)                                                      # the override selects the plain kernel
 

@@ -593,9 +593,10 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
 // finger/object phases of a sweep; everything else is either per-arm or computed identically by both lanes).
 //
 // FAST = true: the same substep with every finger-pad ROW compiled out - no operational-space blocks, no pad warm start,
-// no F phase, nothing of the arm staged in LDS.  It is exact (bit for bit the sweep below: an inactive pad carries
-// 1/diag = 0 and contributes nothing) for as long as no pad of the environment is within the solver margin of the object,
-// and it says so: the return value is "a pad row of this environment is active in this substep".  The fast step kernel
+// no F phase, nothing of the arm staged in LDS.  It is exact (the arithmetic of the sweep below: an inactive pad carries
+// 1/diag = 0 and contributes nothing; the same bits in the host build and in a device build with -ffp-contract=on, the
+// default device build contracts the two instantiations differently: last bits) for as long as no pad of the environment
+// is within the solver margin of the object, and it says so: the return value is "a pad row of this environment is active in this substep".  The fast step kernel
 // runs it on every environment and hands the ones that answer true to a kernel that solves pad rows (xarm_hip.hip,
 // k_step_fast): ~2 % of the environments hold a finger contact, but that is >= 1 lane in most wavefronts, and a wavefront
 // with one such lane sweeps the pad blocks for all 64 (k_step 1.88 ms against 0.74 ms for a contact-free batch).

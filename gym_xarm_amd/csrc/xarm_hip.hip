@@ -147,8 +147,8 @@ __global__ __launch_bounds__(WG) void k_step(KParams P, const float *__restrict_
 }
 
 // The fast step: XarmPickAndPlace.step on the pad-free substep (xk::substep<.., FAST>) for every env.  An env none of
-// whose finger pads comes within the solver margin of the object during the step - ~98 % of them - is finished here,
-// bit for bit as k_step would finish it.  An env with an active pad row stores NOTHING and is appended to eject_list: it is
+// whose finger pads comes within the solver margin of the object during the step - ~98 % of them - is finished here
+// with the arithmetic of k_step (same bits in the host build / with -ffp-contract=on; float32 last bits apart otherwise).  An env with an active pad row stores NOTHING and is appended to eject_list: it is
 // stepped again from its untouched state by k_step_coop_list (or k_step when the list is long).  Why: a wavefront with ONE
 // such lane sweeps the pad blocks for all 64 lanes, and with ~2 % of the envs in contact that is most wavefronts - k_step
 // takes 1.88 ms where a contact-free batch takes 0.74 ms (tools/fastpath_probe.py).  Only the table-slot columns live in

@@ -318,10 +318,12 @@ def test_world_size_invariance_at_the_baseline_split(gx):
 
 def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
     """What a large PickAndPlace batch steps on by default - k_step_fast (the pad-free substep) with the hand-off of the
-    envs that have an active finger-pad row to k_step_coop_list - against the plain k_step: an env that is never handed
-    off is the same BITS (the fast substep is the plain one minus blocks that are no-ops for it), a handed-off env agrees
-    to float32 rounding (it is stepped by the cooperative core); XARM_STEP_PIPELINE=0 and step_coop_limit < 0 select the
-    plain kernel"""
+    envs that have an active finger-pad row to k_step_coop_list - against the plain k_step.  The fast substep is the plain
+    one minus blocks that are no-ops for an env without pad rows: the same bits in the host build (tests/test_hostcore.py)
+    and in a device build with -ffp-contract=on (measured: 71 of 4 096 envs differ after a step, the handed-off ones); the
+    default device build lets LLVM contract the two instantiations differently, so here an env that is never handed off
+    agrees to float32 rounding (last bits of the joint velocities), a handed-off env likewise (cooperative core) until
+    contact chaos separates the trajectories.  XARM_STEP_PIPELINE=0 and step_coop_limit < 0 select the plain kernel."""
     E = 8192
     a = [torch.rand(E, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(70 + j)) * 2 - 1 for j in range(4)]
 
@@ -337,21 +339,18 @@ def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
         return sts, dist
     (fast, _), (plain, dist) = run(step_coop_limit=1), run(step_coop_limit=-1)
     far = torch.ones(E, dtype=torch.bool, device="cuda")
-    n_eq = 0
     for j in range(4):
         # the hand COM travels < 7 cm per step, the pad spheres sit < 9 cm from it and the object's corners < 5.3 cm from its
         # centre: an env whose object centre was more than 22 cm from the hand COM before and after every step so far kept
-        # > 4 cm between pads and object, far outside the 5 mm solver margin, so it was never handed off - same bits.  (That every env with a pad impulse IS handed off, and that the fast step
-        # equals the plain one on every env it accepts, is checked exactly on the host: tests/test_hostcore.py.)
+        # > 4 cm between pads and object, far outside the 5 mm solver margin - it was never handed off
         far &= (dist[j] > 0.22) & (dist[j + 1] > 0.22)
-        eq = (fast[j] == plain[j]).all(dim=1)
-        n_eq += int(eq.sum())
-        assert bool(eq[far].all()), (j, int((~eq[far]).sum()))
         err = (fast[j][:, :31] - plain[j][:, :31]).abs().max(dim=1).values
-        assert float(err.median()) < 1e-5, j                               # bit-equal or float32 rounding
-        if bool((~eq).any()):
-            assert float(err[~eq].median()) < 1e-3, j                      # handed off: float32 rounding, then contact chaos
-    assert int(far.sum()) > 200 and 0.3 * 4 * E < n_eq < 0.995 * 4 * E     # both populations are well represented
+        assert float(err[far].max()) < 2e-4 * (j + 1), (j, float(err[far].max()))   # never handed off: rounding only, no chaos
+        assert float(err.median()) < 1e-5, j
+        assert bool(torch.equal(fast[j][:, 31:34], plain[j][:, 31:34])) and bool(torch.equal(fast[j][:, 52:], plain[j][:, 52:]))   # goals, counters
+        touch_f, touch_p = fast[j][:, 50], plain[j][:, 50]
+        assert float((touch_f != touch_p).float().mean()) < 0.01             # the contact flags agree but for borderline envs
+    assert int(far.sum()) > 200
     monkeypatch.setenv("XARM_STEP_PIPELINE", "0")
     off, _ = run(step_coop_limit=1)
     for x, y in zip(off, plain):

@@ -204,3 +204,16 @@ def test_gpu_a2c_on_handover_dense_nogoal_learns():
     assert venv.dim == 29
     first, last = hist[0]["mean_raw_reward"], hist[-1]["mean_raw_reward"]
     assert first < 0.2 and last > 2 * first and last > 0.3, hist      # past the reach stage: the policy grasps (0.22) and lifts (0.44+)
+
+
+@pytest.mark.gpu
+def test_gpu_a2c_on_pick_and_place_dense_learns_to_reach():
+    """the headline env under its staged `dense` reward (xarm_pick_and_place.py:166-175) on the on-device driver: the mean
+    reward per step rises through the reach stage (0.25 (1 - tanh d), random policy ~0.13) - measured 0.143 / 0.174 / 0.182
+    after 150 / 300 / 450 updates of 4 096 envs at SB3's A2C defaults, 0.22 after 1 500 (tools/learn_probe.py pnp; the grasp
+    stage, 0.5, is not reached in that time)"""
+    from gym_xarm_amd.train import train
+    cfg = {"GUI": False, "num_obj": 1, "reward_type": "dense", "init_grasp_rate": 0.0, "goal_ground_rate": 0.0, "goal_shape": "air"}
+    model, venv, hist = train("XarmPDPickAndPlace-v0", config=cfg, num_envs=4096, updates=400, log_every=100, quiet=True, seed=0)
+    first, last = hist[0]["mean_raw_reward"], hist[-1]["mean_raw_reward"]
+    assert venv.dim == 30 and last > first + 0.02 and last > 0.16, hist

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/sec of XarmPDPickAndPlace-v0 (BASELINE.json `metric`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack|handover2]
                   [--scaling weak|strong] [--repeats R] [--episode-phase desync|lockstep] [--aged-preroll P]
                   [--no-aged] [--no-lockstep] [--no-lazy] [--no-strong] [--no-extras] [--no-cpu-baseline]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -56,6 +56,10 @@ WORKLOADS = {
     "handover": ("XarmPDHandover-v0", 16384, 8, 648, "k_ho_step", "OracleHandover", (16, 30),
                  dict(GUI=False, num_obj=1, same_side_rate=0.5, goal_shape="ground", use_stand=False)),
     "stack": ("XarmPDStackTower-v0", 8192, 8, 1040, "k_st_step", "OracleStackTower", (64, 60), None),
+    # not a BASELINE config: the reference's own test.py configuration (num_obj 2, goal_shape 'any'), same per-GPU size as
+    # config 5; algorithmic bytes by SURVEY 8(d)'s rule: state (36 + 26 + 6 + 4 = 72 f) x 2 + action 32 B + out (42 + 6 + 6 + 3 = 57 f)
+    "handover2": ("XarmHandover-v0", 16384, 8, 836, "k_ho2_step", "OracleHandover", (16, 30),
+                  dict(GUI=False, num_obj=2, same_side_rate=0.5, goal_shape="any", use_stand=False)),
 }
 
 
@@ -66,8 +70,9 @@ WORKLOAD_NAMES = {
     "reach": "XarmReach-v0 (XarmReachEnv, sparse reward; BASELINE config 2)",
     "handover": "XarmPDHandover-v0 (XarmHandover, num_obj=1, goal_shape=ground, same_side_rate=0.5; BASELINE config 5)",
     "stack": "XarmPDStackTower-v0 (XarmStackTowerEnv, three cubes, sparse reward; BASELINE config 4)",
+    "handover2": "XarmHandover-v0 (XarmHandover, num_obj=2, goal_shape=any, same_side_rate=0.5: the reference's test.py:9-15; not a BASELINE config)",
 }
-SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15}   # internal substeps (Handover: 15 ticks of one substep)
+SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15, "handover2": 15}   # internal substeps (Handover: 15 ticks of one substep)
 
 
 def reference_availability():
@@ -88,7 +93,8 @@ def cpu_baseline(workload="pnp"):
     O.lib()
     env_id, _, act_dim, _, _, cls, (sample_envs_per_thread, steps), _ = WORKLOADS[workload]
     cores = max(1, min(os.cpu_count() or 1, 16))
-    envs = [getattr(O, cls)(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread) for k in range(cores)]
+    okw = {"num_obj": 2, "goal_shape": "any"} if workload == "handover2" else {}
+    envs = [getattr(O, cls)(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread, **okw) for k in range(cores)]
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, size=(steps, cores, sample_envs_per_thread, act_dim))
 
@@ -223,7 +229,7 @@ def main():
         # steady state of the workload: envs whose episodes can end early (success: PickAndPlace, Handover) drift apart
         # and reset at a uniform rate; fixed-length episodes (Reach: 25 steps, StackTower: 50, never `done` before)
         # start together and stay together for ever - one bulk reset every T_ep-th step IS their steady state
-        args.episode_phase = "desync" if args.workload in ("pnp", "handover") else "lockstep"
+        args.episode_phase = "desync" if args.workload in ("pnp", "handover", "handover2") else "lockstep"
     if args.episode_phase == "desync":
         # steady state: episode phases uniform over the episode length, keyed by the global env id
         env.set_episode_steps((torch.arange(E, device=dev) + offset) * 7919 % T_ep)
@@ -390,10 +396,10 @@ def main():
             valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction, step kernel only)",
                     "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu, "covers": "step kernel only"}
         reset_kernel_key = {"pnp": "k_reset_coop", "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
-                            "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
+                            "handover": "k_ho_reset", "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
         reset_kernel = {"pnp": "k_reset_coop (<= %d finished envs per call) / k_reset" % reset_limit,
                         "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
-                        "handover": "k_ho_reset", "stack": "k_st_reset"}[args.workload]
+                        "handover": "k_ho_reset", "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
         # reset kernels: algorithmic bytes = state in + out and the fresh obs / goal rows, per finished env
         reset_algo = resets_per_call * (2 * 4 * env_state_dim + 4 * env_out_floats)
         reset_traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (reset_kernel_key, E))

@@ -16,9 +16,9 @@ def _bench():
 def test_workloads_are_consistent(oracle):
     import gym_xarm_amd
     b = _bench()
-    assert set(b.WORKLOADS) == {"pnp", "reach", "handover", "stack"} == set(b.WORKLOAD_NAMES) == set(b.SUBSTEPS)
-    survey_bytes = {"pnp": 452, "reach": 336, "handover": 648, "stack": 1040}
-    default_envs = {"pnp": 65536, "reach": 4096, "handover": 16384, "stack": 8192}     # BASELINE.json configs, per GPU
+    assert set(b.WORKLOADS) == {"pnp", "reach", "handover", "stack", "handover2"} == set(b.WORKLOAD_NAMES) == set(b.SUBSTEPS)
+    survey_bytes = {"pnp": 452, "reach": 336, "handover": 648, "stack": 1040, "handover2": 836}    # SURVEY.md 8(d) (+ its rule for N = 2)
+    default_envs = {"pnp": 65536, "reach": 4096, "handover": 16384, "stack": 8192, "handover2": 16384}     # BASELINE.json configs, per GPU
     for w, (env_id, E, act_dim, nbytes, kernel, cls, sample, cfg) in b.WORKLOADS.items():
         assert env_id in gym_xarm_amd.registered_ids()
         assert hasattr(oracle, cls)

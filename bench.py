@@ -427,7 +427,8 @@ def main():
             # achieved / peak / frac / traffic are the HBM figures the contract asks for - a fused step touches HBM once
             "roofline": {"bound": "valu/latency", "reported_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "%s + %s (one xarm_step call)" % (kernel_name + (" + k_step_coop_list (hand-off)" if kernel_name == "k_step_fast" else ""), reset_kernel),
+                         "kernel": "%s + %s (one xarm_step call)" % (kernel_name + (" + k_step_coop_list (hand-off)" if kernel_name == "k_step_fast" else
+                                                                                   " (+ k_class_hist, k_class_place: class order)" if kernel_name == "k_st_step" else ""), reset_kernel),
                          "kernel_avg_ms": call_ms, "kernel_launches": int(launches),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernels": {kernel_name: {"avg_ms": kstep_ms, "share": kstep_ms / call_ms,

@@ -450,7 +450,7 @@ XARM_HD void pad_columns(const Grp &G, const Setup<T> &S, const LV<T> (&J)[R_G],
 // G (gear), F (pad points).  The table rows never couple to the single-joint rows (A is block diagonal there; only
 // the pad rows touch both), so table row i and single-joint row i - both owned by lane i - are advanced in one PAIR
 // step on packed registers: same arithmetic per row, same order within each block, 14 steps instead of 26.
-#ifdef XC_SWEEP_ITERS
+#if defined(XC_SWEEP_ITERS) && !defined(XARM_SWEEP_VARIANT)
 #define XARM_SWEEP_VARIANT XC_SWEEP_ITERS      // xarm_version() reports it (xarm_hip.hip)
 #endif
 #ifndef XC_SWEEP_ITERS

@@ -51,6 +51,14 @@
 #define XARM_LDS_FENCE() ((void)0)
 #endif
 
+// timing probes only (tools/variant_time.sh): -DXK_SWEEP_ITERS=n builds the one-env-per-lane cores with n solver sweeps, to
+// split a kernel's time into per-substep setup and sweeps; xarm_version() then reports a TIMING VARIANT (xarm_hip.hip)
+#ifdef XK_SWEEP_ITERS
+#define XARM_SWEEP_VARIANT XK_SWEEP_ITERS
+#else
+#define XK_SWEEP_ITERS xm::NUM_ITERATIONS
+#endif
+
 namespace xk {
 
 constexpr int STATE_DIM = 54;
@@ -961,7 +969,7 @@ XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
     // ---------------- projected Gauss-Seidel, rows in the order T, M, L, G, F
     const T mu_p = (T)xm::MU_OBJECT * (st.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
 #pragma unroll 1
-    for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+    for (int it = 0; it < XK_SWEEP_ITERS; it++) {
         XARM_LDS_FENCE(); // keep the S / T reads of this sweep as LDS reads inside the loop
         // (T) object / table points: n = +z, t1 = -y, t2 = +x
 #pragma unroll

@@ -402,7 +402,7 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
     // ---------------- projected Gauss-Seidel: T, BB, (M L G) of this lane's arm, F arm 0, F arm 1
     const T mu_p = (T)xm::MU_OBJECT * (L.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
 #pragma unroll 1
-    for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+    for (int it = 0; it < XK_SWEEP_ITERS; it++) {
         XARM_LDS_FENCE();
         // (T) n = +z, t1 = -y, t2 = +x (btPlaneSpace1 of (0,0,1)); an empty slot is a no-op (1/diag = 0)
 #pragma unroll

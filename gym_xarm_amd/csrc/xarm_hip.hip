@@ -865,6 +865,7 @@ __device__ __forceinline__ void st_load(const KParams &P, int64_t e, int arm, xs
 #pragma unroll
     for (int k = 0; k < 4; k++) L.lam_p[k] = S[(xs::K_LP + 4 * arm + k) * n];
     L.steps = S[xs::K_STEPS * n]; L.episode = S[xs::K_EPISODE * n];
+    L.cls = 0;
 }
 __device__ __forceinline__ void st_store(const KParams &P, int64_t e, int arm, const xs::Lane<float> &L) {
     float *S = P.state + e;
@@ -919,17 +920,47 @@ __global__ __launch_bounds__(WG) void k_st_init(KParams P) {
     xs::lane_init<float>(P.cfg, e, L);
     st_store(P, e, arm, L);
 }
+// class-homogeneous wavefronts (xarm_stack_core.h class_layout): histogram of the per-env class keys, then every env takes
+// the next slot of its class; order[slot] = env is the order k_st_step visits the envs in.  The arrival order inside a
+// class comes from an atomic counter and differs from run to run - it decides which wavefront an env shares, never its
+// result (an env is bitwise independent of its neighbours).
+__global__ void k_class_hist(const uint8_t *__restrict__ key, int64_t n, int *__restrict__ hist) {
+    __shared__ int h[xs::NCLS];
+    if (threadIdx.x < xs::NCLS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) atomicAdd(&h[key[e] & (xs::NCLS - 1)], 1);
+    __syncthreads();
+    if (threadIdx.x < xs::NCLS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_class_place(const uint8_t *__restrict__ key, int64_t n, const int *__restrict__ hist, int *__restrict__ cursor,
+                              int *__restrict__ order, int group) {
+    __shared__ xs::ClassLayout Y;
+    if (threadIdx.x == 0) {
+        int hh[xs::NCLS];
+        for (int c = 0; c < xs::NCLS; c++) hh[c] = hist[c];
+        xs::class_layout(hh, group, Y);
+    }
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int c = key[e] & (xs::NCLS - 1);
+    const int k = atomicAdd(&cursor[c], 1);
+    const int slot = xs::class_slot(Y, c, k);
+    if (slot >= 0 && slot < n) order[slot] = (int)e;   // always true for a histogram of these keys; never write outside
+}
 __global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                int *__restrict__ stale_count) {
+                                                int *__restrict__ stale_count, const int *__restrict__ order, uint8_t *__restrict__ key) {
     __shared__ float smem[xs::LDS_FLOATS * WG];
-    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, slot = t >> 1;
     const int arm = (int)(t & 1);
     if (t == 0 && stale_count) *stale_count = 0;
-    if (e_in >= P.num_envs) return;
+    if (slot >= P.num_envs) return;
+    const int64_t e_in = order ? (int64_t)order[slot] : slot;
     DevLds lds{smem + threadIdx.x};
     xs::Lane<float> L;
     st_load(P, e_in, arm, L);
@@ -943,6 +974,7 @@ __global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restri
     st_write_obs(L, e, arm, obs_out, ag_out, dg_out);
     if (done && P.auto_reset && term_obs) st_write_obs(L, e, arm, term_obs, nullptr, nullptr);
     if (arm == 0) {
+        if (key) key[e] = (uint8_t)L.cls;
         rew_out[e] = reward;
         done_out[e] = done ? 1 : 0;
         succ_out[e] = success ? 1 : 0;
@@ -953,7 +985,8 @@ __global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restri
     }
 }
 __global__ __launch_bounds__(WG) void k_st_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
-                                                 float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+                                                 float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                 uint8_t *__restrict__ key) {
     __shared__ float smem[xs::LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
     const int arm = (int)(t & 1);
@@ -966,6 +999,7 @@ __global__ __launch_bounds__(WG) void k_st_reset(KParams P, const int *__restric
     xs::lane_reset<float, DevLds, DppXchg>(P.cfg, e_in, L, arm, lds, DppXchg());
     const int64_t e = late_index(e_in);
     st_store(P, e, arm, L);
+    if (key && arm == 0) key[e] = (uint8_t)L.cls;
     if (obs_out) st_write_obs(L, e, arm, obs_out, ag_out, dg_out);
 }
 // xarm_stack_tower.py:124-129 over n rows of 9
@@ -999,6 +1033,10 @@ struct xarm_handle {
     int fast_pipeline;   // PickAndPlace, larger batches: k_step_fast + hand-off of the envs with finger-pad rows (1) or k_step (0)
     int *eject_list;     // [E] envs handed off by k_step_fast
     int *eject_count;    // [1]
+    // StackTower: class-homogeneous wavefronts (xarm_stack_core.h class_layout); null when XARM_ST_CLASS_ORDER=0
+    uint8_t *class_key;  // [E] row-set class of each env's last substep
+    int *class_hist;     // [2 * NCLS] histogram, then the per-class arrival counters
+    int *class_order;    // [E] slot -> env
     uint64_t step_index;
     char err[512];
     // timing
@@ -1173,6 +1211,15 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         if (e4 == hipSuccess) e4 = hipMalloc(&h->eject_count, sizeof(int));
         if (e4 == hipSuccess) e4 = hipMemset(h->eject_count, 0, sizeof(int));
     }
+    if (e4 == hipSuccess && stack) {
+        const char *ev = getenv("XARM_ST_CLASS_ORDER");
+        if (!(ev && *ev && atoi(ev) == 0)) {
+            e4 = hipMalloc(&h->class_key, stride);
+            if (e4 == hipSuccess) e4 = hipMalloc(&h->class_hist, sizeof(int) * 2 * xs::NCLS);
+            if (e4 == hipSuccess) e4 = hipMalloc(&h->class_order, sizeof(int) * stride);
+            if (e4 == hipSuccess) e4 = hipMemset(h->class_key, 0, stride);
+        }
+    }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         fail(nullptr, XARM_E_HIP, "xarm_create: hipMalloc failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4))));
         xarm_destroy(h);
@@ -1208,6 +1255,9 @@ int xarm_destroy(xarm_handle *h) {
     if (h->mask_count) hipFree(h->mask_count);
     if (h->eject_list) hipFree(h->eject_list);
     if (h->eject_count) hipFree(h->eject_count);
+    if (h->class_key) hipFree(h->class_key);
+    if (h->class_hist) hipFree(h->class_hist);
+    if (h->class_order) hipFree(h->class_order);
     delete h;
     return XARM_OK;
 }
@@ -1237,12 +1287,12 @@ int xarm_reset(xarm_handle *h, const uint8_t *mask_dev, float *obs_dev, float *a
         k_compact_mask<<<dim3((unsigned)((h->kp.num_envs + 255) / 256)), dim3(256), 0, st>>>(mask_dev, h->kp.num_envs, h->done_list, h->mask_count);
         if (h->cfg.env_kind == XARM_ENV_REACH) launch_reach_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
-        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, h->class_key);
         else launch_pnp_reset(h, h->done_list, h->mask_count, obs_dev, ag_dev, dg_dev, st);
     } else {
         if (h->cfg.env_kind == XARM_ENV_REACH) launch_reach_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
         else if (h->cfg.env_kind == XARM_ENV_HANDOVER) launch_ho_reset(h, 2 * grid, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
-        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev);
+        else if (h->cfg.env_kind == XARM_ENV_STACK_TOWER) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, nullptr, nullptr, obs_dev, ag_dev, dg_dev, h->class_key);
         else launch_pnp_reset(h, nullptr, nullptr, obs_dev, ag_dev, dg_dev, st);
     }
     HIPCHK(h, hipGetLastError());
@@ -1270,9 +1320,16 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         HIPCHK(h, hipGetLastError());
         return XARM_OK;
     }
-    if (stack)
+    if (stack) {
+        if (h->class_key) {
+            HIPCHK(h, hipMemsetAsync(h->class_hist, 0, sizeof(int) * 2 * xs::NCLS, st));
+            const unsigned cg = (unsigned)((h->kp.num_envs + 255) / 256);
+            k_class_hist<<<dim3(cg), dim3(256), 0, st>>>(h->class_key, h->kp.num_envs, h->class_hist);
+            k_class_place<<<dim3(cg), dim3(256), 0, st>>>(h->class_key, h->kp.num_envs, h->class_hist, h->class_hist + xs::NCLS, h->class_order, WG / 2);
+        }
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                       terminal_obs_dev, h->done_list, cnt, stale);
+                                                       terminal_obs_dev, h->done_list, cnt, stale, h->class_order, h->class_key);
+    }
     else if (handover && h->cfg.num_obj == 2)
         k_ho2_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                         terminal_obs_dev, h->done_list, cnt, stale);
@@ -1312,7 +1369,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (h->kp.auto_reset) {
         if (reach) launch_reach_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (handover) launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
-        else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev);
+        else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->class_key);
         else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
     }
     if (timed) { HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
@@ -1421,6 +1478,13 @@ int xarm_timing_read_reset(xarm_handle *h, double *reset_ms_total, int64_t *laun
     timing_flush(h);
     *reset_ms_total = h->ev_reset_ms;
     *launches = h->ev_launches;
+    return XARM_OK;
+}
+int xarm_class_keys(xarm_handle *h, uint8_t *keys_dev, void *stream) {
+    if (!h || !keys_dev) return XARM_E_INVALID;
+    DEVGUARD(h);
+    if (!h->class_key) return fail(h, XARM_E_INVALID, "%s", "xarm_class_keys: StackTower handles with the class order enabled only");
+    HIPCHK(h, hipMemcpyAsync(keys_dev, h->class_key, (size_t)h->kp.num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return XARM_OK;
 }
 int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit) {

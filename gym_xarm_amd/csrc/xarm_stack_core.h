@@ -52,7 +52,52 @@ template <typename T> struct Lane {
     T lam_t[NOBJ][8];
     T lam_p[4];
     T steps, episode;
+    int cls;   // row-set class of the last substep (class_key below); scheduling hint, not part of the state
 };
+
+// ---- class-homogeneous wavefronts.  A wavefront sweeps the UNION of the row sets its 32 environments need (each
+// wave-uniform skip is a ballot over the lanes), and the launch lasts as long as its slowest wavefront: with the envs in
+// arrival order nearly every wavefront holds some env with cube/cube contact in each of the three pairs and some env with
+// a finger contact, so all pay for everything (k_st_step 5.6 ms), although 88 % of the envs have no cube/cube contact
+// at all and ~0.05 % have two pairs (tools/st_pairs.py).  An env's result does not depend on its neighbours (bitwise,
+// tests/test_edge_cases.py), so the step kernel may visit the envs in any order: they are grouped by the row sets their
+// last substep used - class key: bits 0-2 cube pairs (0,1) (0,2) (1,2) in contact, bit 3 / 4 a finger pad of arm 0 / 1
+// active, bits 5-7 the pair's manifold has more than two points (edge against face: 2, face against face: 4; the sweep
+// skips the point slots no env of the wavefront fills) - and every non-empty class other than 0 starts on a wavefront
+// boundary, topped up with class-0 envs (which add nothing to a union).  A stale key (the contact set changed during the
+// step) only makes that wavefront slower.
+constexpr int NCLS = 256;
+struct ClassLayout { int start[NCLS], hole_start[NCLS], hole_len[NCLS], tail_start; bool aligned; };
+// slots [0, n) for the envs of each class, from the class histogram; `group` = envs per wavefront.  Class c > 0 occupies
+// [start[c], start[c] + hist[c]); the hole up to the next multiple of `group` and the tail after the last class are
+// filled by class 0 in order.  Without enough class-0 envs to fill the holes: plain contiguous order (aligned = false).
+XARM_HD void class_layout(const int (&hist)[NCLS], int group, ClassLayout &Y) {
+    int pos = 0, holes = 0;
+    for (int c = 1; c < NCLS; c++) {
+        Y.start[c] = pos;
+        const int end = pos + hist[c];
+        const int al = hist[c] > 0 ? (end + group - 1) / group * group : end;
+        Y.hole_start[c] = end; Y.hole_len[c] = al - end;
+        holes += al - end;
+        pos = al;
+    }
+    Y.aligned = holes <= hist[0];
+    if (!Y.aligned) {
+        pos = 0;
+        for (int c = 1; c < NCLS; c++) { Y.start[c] = pos; pos += hist[c]; Y.hole_start[c] = pos; Y.hole_len[c] = 0; }
+    }
+    Y.start[0] = 0; Y.hole_start[0] = 0; Y.hole_len[0] = 0;
+    Y.tail_start = pos;
+}
+// slot of the k-th env (arrival order) of class c
+XARM_HD int class_slot(const ClassLayout &Y, int c, int k) {
+    if (c != 0) return Y.start[c] + k;
+    for (int j = 1; j < NCLS; j++) {
+        if (k < Y.hole_len[j]) return Y.hole_start[j] + k;
+        k -= Y.hole_len[j];
+    }
+    return Y.tail_start + k;
+}
 
 template <typename T> XARM_HD T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 template <typename T> XARM_HD V3<T> sel3v(int i, V3<T> a, V3<T> b, V3<T> c) { return mk<T>(sel3(i, a.x, b.x, c.x), sel3(i, a.y, b.y, c.y), sel3(i, a.z, b.z, c.z)); }
@@ -306,6 +351,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     // ---------------- (BB) cube / cube manifolds -> LDS
     const T mu_bb = (T)(xm::MU_OBJECT * xm::MU_OBJECT);
     bool bb_any = false, pair_act[NPAIR] = {false, false, false};
+    int pair_np[NPAIR] = {0, 0, 0};
 #pragma unroll
     for (int pr = 0; pr < NPAIR; pr++) {
         const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
@@ -321,7 +367,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             T dist[4];
             const int np = near ? cube_cube<T, Lds>(cb[a], Rb[a], cb[b], Rb[b], h, (T)xm::SOLVER_MARGIN, pts, nrm, dist, lds) : 0;
             if (np > 0) {
-                bb_any = true; pair_act[pr] = true;
+                bb_any = true; pair_act[pr] = true; pair_np[pr] = np;
                 const V3<T> t1 = xk::plane_space(nrm), t2 = cross(nrm, t1);
                 lds[base + 0] = nrm.x; lds[base + 1] = nrm.y; lds[base + 2] = nrm.z;
                 lds[base + 3] = t1.x; lds[base + 4] = t1.y; lds[base + 5] = t1.z;
@@ -520,6 +566,12 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     for (int idx = 0; idx < NP; idx++) mymask |= pp[idx].invd[0] != (T)0 ? (1 << pc[idx]) : 0;
     const int othermask = (int)xchg.partner((T)mymask);
     const bool seq = XARM_ANY_X((mymask & othermask) != 0);
+    L.cls = (pair_act[0] ? 1 : 0) | (pair_act[1] ? 2 : 0) | (pair_act[2] ? 4 : 0) |
+            ((arm == 0 ? mymask : othermask) != 0 ? 8 : 0) | ((arm == 1 ? mymask : othermask) != 0 ? 16 : 0) |
+            (pair_np[0] > 2 ? 32 : 0) | (pair_np[1] > 2 ? 64 : 0) | (pair_np[2] > 2 ? 128 : 0);
+    bool pair_wide[NPAIR];   // wave-uniform: some env of the wavefront has a third point in this pair
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; pr++) pair_wide[pr] = XARM_ANY(pair_np[pr] > 2);
     XARM_LDS_FENCE();
 
     bool la_lane = false;
@@ -547,7 +599,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     // ---------------- projected Gauss-Seidel: T, BB, (M L G) of this lane's arm, F arm 0, F arm 1
     const T mu_p = (T)(xm::MU_OBJECT * xm::MU_FINGER);
 #pragma unroll 1
-    for (int it = 0; it < xm::NUM_ITERATIONS; it++) {
+    for (int it = 0; it < XK_SWEEP_ITERS; it++) {
         XARM_LDS_FENCE();
         // (T) n = +z, t1 = -y, t2 = +x
 #pragma unroll
@@ -636,10 +688,13 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                 if (!XARM_ANY(pair_act[pr])) continue;
                 const V3<T> n = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]), t1 = mk<T>(lds[base + 3], lds[base + 4], lds[base + 5]);
                 const V3<T> t2 = cross(n, t1);
-                // all four slots of an active pair, unrolled and unconditional (an empty slot is a no-op): the LDS reads
-                // of the next point are issued while the current one is solved
+                // the slots some env of the wavefront fills (points are compacted to the front; an empty slot is a no-op),
+                // unrolled: the LDS reads of the next point are issued while the current one is solved.  Slots 2-3 are
+                // skipped together: with the envs in class order (above) the wavefronts of the edge-contact classes never
+                // see a third point; in arrival order this test is almost never true and costs ~nothing
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
+                    if (q >= 2 && !pair_wide[pr]) continue;
                     const int pb = base + 6 + q * BB_W;
                     const T e0 = lds[pb + 10];
                     const V3<T> rA = mk<T>(lds[pb + 0], lds[pb + 1], lds[pb + 2]), rB = mk<T>(lds[pb + 3], lds[pb + 4], lds[pb + 5]);
@@ -888,6 +943,7 @@ template <typename T> XARM_HD void lane_init(const EnvCfg &cfg, int64_t env, Lan
 #pragma unroll
     for (int i = 0; i < 9; i++) L.qt[i] = L.q[i];   // no motor command yet: hold the init pose
     L.steps = L.episode = (T)0;
+    L.cls = 0;
     T u[8];
     draws(cfg, env, 0, u);
     sample_objects(u, L);

@@ -280,6 +280,13 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, self._L.xarm_kernel_limits(self._h, C.byref(r), C.byref(s)), "xarm_kernel_limits")
         return r.value, s.value
 
+    def class_keys(self):
+        """uint8 [E] (StackTower): the row-set class of every env's last substep - what the step kernel groups the envs by
+        (include/xarm_hip.h xarm_class_keys)"""
+        out = torch.empty(self.num_envs, device=self.device, dtype=torch.uint8)
+        _native.check(self._L, self._h, self._L.xarm_class_keys(self._h, _ptr(out), self._stream()), "xarm_class_keys")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._L.xarm_destroy(self._h)

@@ -249,6 +249,15 @@ class HostCore:
                             self._p(obs), self._p(ag), self._p(dg))
         return st, obs, ag, dg
 
+    def class_order(self, key, group=32):
+        """(order, aligned): the StackTower step kernel's visiting order for these class keys"""
+        k = np.ascontiguousarray(key, dtype=np.uint8)
+        order = np.zeros(k.shape[0], np.int32)
+        self.L.xh_class_order.restype = C.c_int
+        rc = self.L.xh_class_order(k.ctypes.data_as(C.c_void_p), C.c_int64(k.shape[0]), C.c_int(group), order.ctypes.data_as(C.c_void_p))
+        assert rc >= 0, "class_slot produced an out-of-range or duplicate slot"
+        return order, bool(rc)
+
     def box_box(self, pA, RA, hA, pB, RB, hB, margin=0.005, f32=0):
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (pA, RA, hA, pB, RB, hB)]
         pts, nrm, dist = np.zeros((4, 3)), np.zeros(3), np.zeros(4)

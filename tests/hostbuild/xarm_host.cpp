@@ -471,6 +471,22 @@ void xh_st_reset(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double 
     auto c = scfg(seed, off, rt);
     if (f32) st_run<float>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0); else st_run<double>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0);
 }
+// class-homogeneous visiting order of the StackTower step kernel (xs::class_layout / class_slot, as k_class_hist + k_class_place
+// run them, with the envs arriving in index order): order[slot] = env; returns 1 when the classes are wavefront-aligned
+int xh_class_order(const uint8_t *key, int64_t n, int group, int32_t *order) {
+    int hist[xs::NCLS] = {0}, cursor[xs::NCLS] = {0};
+    for (int64_t e = 0; e < n; e++) hist[key[e] & (xs::NCLS - 1)]++;
+    xs::ClassLayout Y;
+    xs::class_layout(hist, group, Y);
+    for (int64_t e = 0; e < n; e++) order[e] = -1;
+    for (int64_t e = 0; e < n; e++) {
+        const int c = key[e] & (xs::NCLS - 1);
+        const int slot = xs::class_slot(Y, c, cursor[c]++);
+        if (slot < 0 || slot >= n || order[slot] != -1) return -1;
+        order[slot] = (int32_t)e;
+    }
+    return Y.aligned ? 1 : 0;
+}
 // cube/cube manifold alone (R row-major, column k = axis k, as the oracle's xo_box_box)
 int xh_cube_cube(int f32, const double *pA, const double *RA, const double *pB, const double *RB, double h, double margin, double *pts, double *nrm, double *dist) {
     int n;

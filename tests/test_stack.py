@@ -374,3 +374,60 @@ def test_stack_gpu_full_size_properties_8192():
     assert bool((st[:, 102:134] >= 0).all())                                          # normal impulses never pull
     assert bool((steps[:quarter] == 2).all()) and bool((steps[quarter:] == 4).all())  # reset inside call 2, then 2 more steps
     assert bool(((full[2] == 0) | (full[2] == -1)).all())                             # sparse reward (:124-127)
+
+
+def test_class_order_is_a_permutation_with_one_class_per_wavefront(hostcore):
+    """xs::class_layout / class_slot (the visiting order of k_st_step): every env appears once; while class 0 can fill
+    the holes each wavefront-sized group holds at most ONE class other than 0; without enough class-0 envs the order
+    falls back to plain contiguous classes - still a permutation"""
+    rng = np.random.default_rng(0)
+    for n, p0 in ((8192, 0.88), (1000, 0.9), (37, 0.5), (1, 1.0), (64, 0.0), (5000, 0.05), (4096, 1.0)):
+        key = np.where(rng.random(n) < p0, 0, rng.choice([1, 2, 4, 9, 17, 33, 3, 200, 255], n)).astype(np.uint8)
+        order, aligned = hostcore.class_order(key, 32)
+        assert np.array_equal(np.sort(order), np.arange(n))
+        ko = key[order]
+        holes = sum((-int((key == c).sum())) % 32 for c in range(1, 256) if (key == c).any())
+        assert aligned == (holes <= int((key == 0).sum()))
+        if aligned:
+            for g in range(0, n, 32):
+                assert len(set(ko[g:g + 32].tolist()) - {0}) <= 1, "group %d mixes classes" % (g // 32)
+        else:
+            nz = ko[ko != 0]
+            assert np.all(np.diff(nz.astype(int)) >= 0) and np.all(ko[:nz.size] != 0)
+
+
+@pytest.mark.gpu
+def test_gpu_class_order_changes_nothing_but_the_time():
+    """k_st_step visits the envs grouped by row-set class (xarm_stack_core.h class_layout) unless XARM_ST_CLASS_ORDER=0:
+    states, observations, rewards and done flags are bitwise those of the plain order, through resets"""
+    import torch
+    import gym_xarm_amd
+    E = 3000
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["XARM_ST_CLASS_ORDER"] = flag
+        try:
+            env = gym_xarm_amd.make("XarmPDStackTower-v0", num_envs=E, seed=4)
+        finally:
+            del os.environ["XARM_ST_CLASS_ORDER"]
+        env.reset()
+        s = env.get_state()
+        # a third of the envs with cubes side by side / stacked, so that several classes exist from the first step on
+        s[: E // 6, 54:63] = torch.tensor([-0.05, 0.0, 0.025, 0.0, 0.0, 0.025, 0.05, 0.0, 0.025], device=env.device)
+        s[E // 6: E // 3, 54:63] = torch.tensor([0.0, 0.1, 0.025, 0.0, 0.1, 0.075, 0.2, 0.0, 0.025], device=env.device)
+        s[: E // 3, 63:75] = torch.tensor([0.0, 0.0, 0.0, 1.0] * 3, device=env.device)
+        s[: E // 3, 75:93] = 0
+        env.set_state(s)
+        env.set_episode_steps(torch.arange(E, device=env.device) % 100)     # time-limit resets inside the run
+        gen = torch.Generator(device=env.device)
+        gen.manual_seed(2)
+        rec = []
+        for _ in range(8):
+            a = torch.rand(E, 8, device=env.device, generator=gen) * 2 - 1
+            obs, rew, done, info = env.step(a)
+            rec.append(torch.cat([obs["observation"], obs["achieved_goal"], obs["desired_goal"], rew[:, None], done[:, None].float(),
+                                  env.get_state()], dim=1).clone())
+        outs.append(torch.stack(rec))
+        env.close()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])

@@ -19,6 +19,15 @@ for tag, kw in (("num_obj 1", dict()), ("num_obj 2", dict(config=dict(GUI=False,
     up = z.clone(); up[:, 2] = 1; up[:, 6] = 1
     for _ in range(6): env.step(up)
     run(tag + ": arms up, stick resting", env, lambda i: z)
+    if kw:   # two sticks: how much of that is the stick/stick manifold (state layout: xarm_handover2_core.h G_BP = 38 ...)
+        s0 = env.get_state()
+        s = s0.clone()
+        s[:, 38:41] = torch.tensor([-0.3, -0.2, 0.02], device=env.device); s[:, 41:44] = torch.tensor([0.3, 0.2, 0.02], device=env.device)
+        s[:, 44:52] = torch.tensor([0., 0, 0, 1, 0, 0, 0, 1], device=env.device); s[:, 52:64] = 0
+        env.set_state(s)
+        run(tag + ": arms up, sticks far apart", env, lambda i: z, n=5)
+        s[:, 40] = 5.0; s[:, 43] = 6.0; env.set_state(s)
+        run(tag + ": arms up, sticks in free fall", env, lambda i: z, n=3)
     g = torch.Generator(device=env.device); g.manual_seed(0)
     acts = [torch.rand(E, 8, device=env.device, generator=g) * 2 - 1 for _ in range(8)]
     env.reset()

@@ -936,6 +936,8 @@ __global__ void k_class_hist(const uint8_t *__restrict__ key, int64_t n, int *__
 __global__ void k_class_place(const uint8_t *__restrict__ key, int64_t n, const int *__restrict__ hist, int *__restrict__ cursor,
                               int *__restrict__ order, int group) {
     __shared__ xs::ClassLayout Y;
+    __shared__ int cnt[xs::NCLS], base[xs::NCLS];
+    if (threadIdx.x < xs::NCLS) cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         int hh[xs::NCLS];
         for (int c = 0; c < xs::NCLS; c++) hh[c] = hist[c];
@@ -943,10 +945,15 @@ __global__ void k_class_place(const uint8_t *__restrict__ key, int64_t n, const 
     }
     __syncthreads();
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = e < n ? (int)(key[e] & (xs::NCLS - 1)) : 0;
+    // arrival number inside the class: rank inside the block (LDS counter), one global atomic per block and class -
+    // thousands of class-0 envs on one global counter cost 90 us per call
+    const int local = e < n ? atomicAdd(&cnt[c], 1) : 0;
+    __syncthreads();
+    if (threadIdx.x < xs::NCLS && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
     if (e >= n) return;
-    const int c = key[e] & (xs::NCLS - 1);
-    const int k = atomicAdd(&cursor[c], 1);
-    const int slot = xs::class_slot(Y, c, k);
+    const int slot = xs::class_slot(Y, c, base[c] + local);
     if (slot >= 0 && slot < n) order[slot] = (int)e;   // always true for a histogram of these keys; never write outside
 }
 __global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,

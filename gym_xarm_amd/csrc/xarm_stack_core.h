@@ -62,11 +62,11 @@ template <typename T> struct Lane {
 // at all and ~0.05 % have two pairs (tools/st_pairs.py).  An env's result does not depend on its neighbours (bitwise,
 // tests/test_edge_cases.py), so the step kernel may visit the envs in any order: they are grouped by the row sets their
 // last substep used - class key: bits 0-2 cube pairs (0,1) (0,2) (1,2) in contact, bit 3 / 4 a finger pad of arm 0 / 1
-// active, bits 5-7 the pair's manifold has more than two points (edge against face: 2, face against face: 4; the sweep
-// skips the point slots no env of the wavefront fills) - and every non-empty class other than 0 starts on a wavefront
-// boundary, topped up with class-0 envs (which add nothing to a union).  A stale key (the contact set changed during the
-// step) only makes that wavefront slower.
-constexpr int NCLS = 256;
+// active - and every non-empty class other than 0 starts on a wavefront boundary, topped up with class-0 envs (which
+// add nothing to a union).  A stale key (the contact set changed during the step) only makes that wavefront slower.
+// (Also keying on "manifold wider than two points" and skipping point slots 2-3 per wavefront was measured: no gain, the
+// contacts of these axis-aligned cubes are face against face.)
+constexpr int NCLS = 32;
 struct ClassLayout { int start[NCLS], hole_start[NCLS], hole_len[NCLS], tail_start; bool aligned; };
 // slots [0, n) for the envs of each class, from the class histogram; `group` = envs per wavefront.  Class c > 0 occupies
 // [start[c], start[c] + hist[c]); the hole up to the next multiple of `group` and the tail after the last class are
@@ -351,7 +351,6 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     // ---------------- (BB) cube / cube manifolds -> LDS
     const T mu_bb = (T)(xm::MU_OBJECT * xm::MU_OBJECT);
     bool bb_any = false, pair_act[NPAIR] = {false, false, false};
-    int pair_np[NPAIR] = {0, 0, 0};
 #pragma unroll
     for (int pr = 0; pr < NPAIR; pr++) {
         const int a = pr == 2 ? 1 : 0, b = pr == 0 ? 1 : 2;
@@ -367,7 +366,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
             T dist[4];
             const int np = near ? cube_cube<T, Lds>(cb[a], Rb[a], cb[b], Rb[b], h, (T)xm::SOLVER_MARGIN, pts, nrm, dist, lds) : 0;
             if (np > 0) {
-                bb_any = true; pair_act[pr] = true; pair_np[pr] = np;
+                bb_any = true; pair_act[pr] = true;
                 const V3<T> t1 = xk::plane_space(nrm), t2 = cross(nrm, t1);
                 lds[base + 0] = nrm.x; lds[base + 1] = nrm.y; lds[base + 2] = nrm.z;
                 lds[base + 3] = t1.x; lds[base + 4] = t1.y; lds[base + 5] = t1.z;
@@ -567,11 +566,7 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
     const int othermask = (int)xchg.partner((T)mymask);
     const bool seq = XARM_ANY_X((mymask & othermask) != 0);
     L.cls = (pair_act[0] ? 1 : 0) | (pair_act[1] ? 2 : 0) | (pair_act[2] ? 4 : 0) |
-            ((arm == 0 ? mymask : othermask) != 0 ? 8 : 0) | ((arm == 1 ? mymask : othermask) != 0 ? 16 : 0) |
-            (pair_np[0] > 2 ? 32 : 0) | (pair_np[1] > 2 ? 64 : 0) | (pair_np[2] > 2 ? 128 : 0);
-    bool pair_wide[NPAIR];   // wave-uniform: some env of the wavefront has a third point in this pair
-#pragma unroll
-    for (int pr = 0; pr < NPAIR; pr++) pair_wide[pr] = XARM_ANY(pair_np[pr] > 2);
+            ((arm == 0 ? mymask : othermask) != 0 ? 8 : 0) | ((arm == 1 ? mymask : othermask) != 0 ? 16 : 0);
     XARM_LDS_FENCE();
 
     bool la_lane = false;
@@ -688,13 +683,10 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                 if (!XARM_ANY(pair_act[pr])) continue;
                 const V3<T> n = mk<T>(lds[base + 0], lds[base + 1], lds[base + 2]), t1 = mk<T>(lds[base + 3], lds[base + 4], lds[base + 5]);
                 const V3<T> t2 = cross(n, t1);
-                // the slots some env of the wavefront fills (points are compacted to the front; an empty slot is a no-op),
-                // unrolled: the LDS reads of the next point are issued while the current one is solved.  Slots 2-3 are
-                // skipped together: with the envs in class order (above) the wavefronts of the edge-contact classes never
-                // see a third point; in arrival order this test is almost never true and costs ~nothing
+                // all four slots of an active pair, unrolled and unconditional (an empty slot is a no-op): the LDS reads
+                // of the next point are issued while the current one is solved
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    if (q >= 2 && !pair_wide[pr]) continue;
                     const int pb = base + 6 + q * BB_W;
                     const T e0 = lds[pb + 10];
                     const V3<T> rA = mk<T>(lds[pb + 0], lds[pb + 1], lds[pb + 2]), rB = mk<T>(lds[pb + 3], lds[pb + 4], lds[pb + 5]);

@@ -152,7 +152,7 @@ int xarm_timing_read_reset(xarm_handle *h, double *reset_kernels_ms_total, int64
 int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit);
 
 /* StackTower: the row-set class each env's last substep fell into, uint8 [E] (bits 0-2 cube pairs (0,1) (0,2) (1,2) in
- * contact, bit 3 / 4 a finger pad of arm 0 / 1 active, bits 5-7 the pair's manifold has more than two points).  The step
+ * contact, bit 3 / 4 a finger pad of arm 0 / 1 active).  The step
  * kernel visits the envs grouped by this key so that a wavefront sweeps one class's rows, not the union of 32 unrelated
  * envs' (csrc/xarm_stack_core.h "class-homogeneous wavefronts"); an env's result does not depend on the order.
  * XARM_ST_CLASS_ORDER=0 in the environment at xarm_create keeps the arrival order (then, and for the other env kinds,

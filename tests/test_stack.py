@@ -382,11 +382,11 @@ def test_class_order_is_a_permutation_with_one_class_per_wavefront(hostcore):
     falls back to plain contiguous classes - still a permutation"""
     rng = np.random.default_rng(0)
     for n, p0 in ((8192, 0.88), (1000, 0.9), (37, 0.5), (1, 1.0), (64, 0.0), (5000, 0.05), (4096, 1.0)):
-        key = np.where(rng.random(n) < p0, 0, rng.choice([1, 2, 4, 9, 17, 33, 3, 200, 255], n)).astype(np.uint8)
+        key = np.where(rng.random(n) < p0, 0, rng.choice([1, 2, 4, 9, 17, 3, 24, 31], n)).astype(np.uint8)
         order, aligned = hostcore.class_order(key, 32)
         assert np.array_equal(np.sort(order), np.arange(n))
         ko = key[order]
-        holes = sum((-int((key == c).sum())) % 32 for c in range(1, 256) if (key == c).any())
+        holes = sum((-int((key == c).sum())) % 32 for c in range(1, 32) if (key == c).any())
         assert aligned == (holes <= int((key == 0).sum()))
         if aligned:
             for g in range(0, n, 32):

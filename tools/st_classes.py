@@ -18,8 +18,7 @@ probe = gym_xarm_amd.make("XarmPDStackTower-v0", num_envs=E, seed=0, auto_reset=
 probe.reset()
 def name(k):
     pairs = [p for b, p in ((1, "01"), (2, "02"), (4, "12")) if k & b]
-    wide = [p for b, p in ((32, "01"), (64, "02"), (128, "12")) if k & b]
-    return "pairs[%s] wide[%s] pads[%s%s]" % (",".join(pairs), ",".join(wide), "a" if k & 8 else "", "b" if k & 16 else "")
+    return "pairs[%s] pads[%s%s]" % (",".join(pairs), "a" if k & 8 else "", "b" if k & 16 else "")
 rows = []
 for k in sorted(set(keys.tolist())):
     idx = (keys == k).nonzero()[:, 0]

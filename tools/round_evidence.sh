@@ -16,6 +16,7 @@ python bench.py --envs-per-gpu 4096 --no-cpu-baseline --no-lazy --no-lockstep >>
 python bench.py --workload reach >> $L 2>> gpurun_out/${TAG}_bench.err
 python bench.py --workload handover >> $L 2>> gpurun_out/${TAG}_bench.err
 python bench.py --workload stack >> $L 2>> gpurun_out/${TAG}_bench.err
+python bench.py --workload handover2 >> $L 2>> gpurun_out/${TAG}_bench.err
 python - $L <<'PY'
 import json, sys
 for l in open(sys.argv[1]):

@@ -1039,7 +1039,13 @@ struct xarm_handle {
     int coop_step_limit; // PickAndPlace: batches of at most this many envs step on k_step_coop
     int fast_pipeline;   // PickAndPlace, larger batches: k_step_fast + hand-off of the envs with finger-pad rows (1) or k_step (0)
     int *eject_list;     // [E] envs handed off by k_step_fast
-    int *eject_count;    // [1]
+    int *eject_count;    // [2]: hand-off count, count of episodes that ended in the hand-off kernels
+    // the two reset launches of a pipelined step (xarm_step): episodes that ended in k_step_fast are reset on `side`
+    // while the hand-off still runs on the caller's stream, the few that end in the hand-off after it
+    int *done_list_b;    // [E] episodes that ended in the hand-off kernels
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    int reset_overlap;
     // StackTower: class-homogeneous wavefronts (xarm_stack_core.h class_layout); null when XARM_ST_CLASS_ORDER=0
     uint8_t *class_key;  // [E] row-set class of each env's last substep
     int *class_hist;     // [2 * NCLS] histogram, then the per-class arrival counters
@@ -1215,8 +1221,16 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
     if (e4 == hipSuccess && h->fast_pipeline) {
         e4 = hipMalloc(&h->eject_list, sizeof(int) * stride);
-        if (e4 == hipSuccess) e4 = hipMalloc(&h->eject_count, sizeof(int));
-        if (e4 == hipSuccess) e4 = hipMemset(h->eject_count, 0, sizeof(int));
+        if (e4 == hipSuccess) e4 = hipMalloc(&h->eject_count, sizeof(int) * 2);
+        if (e4 == hipSuccess) e4 = hipMemset(h->eject_count, 0, sizeof(int) * 2);
+        if (e4 == hipSuccess) e4 = hipMalloc(&h->done_list_b, sizeof(int) * stride);
+        const char *ev = getenv("XARM_RESET_OVERLAP");
+        if (e4 == hipSuccess && cfg->auto_reset && !(ev && *ev && atoi(ev) == 0)) {
+            e4 = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+            if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+            if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+            h->reset_overlap = e4 == hipSuccess;
+        }
     }
     if (e4 == hipSuccess && stack) {
         const char *ev = getenv("XARM_ST_CLASS_ORDER");
@@ -1262,6 +1276,10 @@ int xarm_destroy(xarm_handle *h) {
     if (h->mask_count) hipFree(h->mask_count);
     if (h->eject_list) hipFree(h->eject_list);
     if (h->eject_count) hipFree(h->eject_count);
+    if (h->done_list_b) hipFree(h->done_list_b);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     if (h->class_key) hipFree(h->class_key);
     if (h->class_hist) hipFree(h->class_hist);
     if (h->class_order) hipFree(h->class_order);
@@ -1316,6 +1334,8 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     const unsigned grid = (unsigned)(h->kp.stride / WG);
     int *cnt = h->done_count + (h->step_index & 1), *stale = h->done_count + ((h->step_index + 1) & 1);
     const bool timed = h->timing && h->ev_created;
+    bool pipelined = false;
+    const bool overlap = h->reset_overlap && h->kp.auto_reset;
     if (timed && h->ev_n == xarm_handle::NEV) timing_flush(h);
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
     const bool reach = h->cfg.env_kind == XARM_ENV_REACH, handover = h->cfg.env_kind == XARM_ENV_HANDOVER;
@@ -1358,22 +1378,38 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else if (h->fast_pipeline) {
         // every env on the pad-free fast step; the ones with an active finger-pad row are handed off, untouched, to the
         // cooperative kernel (lists of at most eject_coop_cap envs) or to k_step (longer lists) - both launched, the one
-        // out of its range exits at once (the count lives on the device)
-        HIPCHK(h, hipMemsetAsync(h->eject_count, 0, sizeof(int), st));
+        // out of its range exits at once (the count lives on the device).  Episodes that end in the hand-off go to a
+        // list of their own (done_list_b): the reset of the ~98 % that ended in k_step_fast need not wait for it.
+        pipelined = true;
+        HIPCHK(h, hipMemsetAsync(h->eject_count, 0, sizeof(int) * 2, st));
         k_step_fast<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                      terminal_obs_dev, h->done_list, cnt, stale, h->eject_list, h->eject_count);
+        if (overlap) {
+            // a reset is six sequential ticks of latency on a few hundred wavefronts (2.9 ms), the hand-off 0.55 ms on a
+            // few hundred others: started now on the side stream, the first reset overlaps the hand-off, and the second -
+            // a handful of envs, whose slowest wavefront is rarely a slow one - is what the call waits for
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->side);
+            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+        }
         const int64_t cap = h->kp.num_envs < (int64_t)h->kp.eject_coop_cap ? h->kp.num_envs : (int64_t)h->kp.eject_coop_cap;
         const unsigned cgrid = (unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS) < 1024u ? (unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS) : 1024u;
+        // without the side stream (XARM_RESET_OVERLAP=0): one list, one reset after the hand-off
+        int *list_b = overlap ? h->done_list_b : h->done_list, *cnt_b = overlap ? h->eject_count + 1 : cnt;
         k_step_coop_list<<<dim3(cgrid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                           terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
+                                                           terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
         if (h->kp.num_envs > cap)
             k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                    terminal_obs_dev, h->done_list, cnt, nullptr, h->eject_list, h->eject_count);
+                                                    terminal_obs_dev, list_b, cnt_b, nullptr, h->eject_list, h->eject_count);
     } else
         k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                 terminal_obs_dev, h->done_list, cnt, stale, nullptr, nullptr);
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
-    if (h->kp.auto_reset) {
+    if (h->kp.auto_reset && pipelined && overlap) {
+        launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    } else if (h->kp.auto_reset) {
         if (reach) launch_reach_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (handover) launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
         else if (stack) k_st_reset<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->class_key);

@@ -99,6 +99,9 @@ typedef struct xarm_config {
  * reset family, depends on a COUNT and therefore on the shard - is only ever crossed by configurations that start most
  * episodes in the gripper (init_grasp_rate) */
 #define XARM_EJECT_COOP_CAP 32768
+/* A pipelined step with auto-reset resets the episodes that ended in the fast kernel on a side stream owned by the handle,
+ * in parallel with the hand-off, and joins it (event wait) before its work on the caller's stream ends: the caller sees one
+ * stream-ordered call.  XARM_RESET_OVERLAP=0 in the environment at xarm_create keeps everything on the caller's stream. */
 /* PickAndPlace handles of at most this many envs step on the cooperative kernel as well (env XARM_STEP_COOP_LIMIT) */
 #define XARM_STEP_COOP_LIMIT_DEFAULT 8192
 

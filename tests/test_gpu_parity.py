@@ -316,6 +316,32 @@ def test_world_size_invariance_at_the_baseline_split(gx):
     assert float(err.median()) < 1e-4 and bool(torch.equal(dflt[0][:, 31:34], full[0][off:off + n, 31:34]))
 
 
+def test_overlapped_reset_changes_nothing_but_the_time(gx, monkeypatch):
+    """A pipelined PickAndPlace step resets the episodes that ended in k_step_fast on a side stream while the hand-off still
+    runs, and those that ended in the hand-off after it (two lists, two launches, joined before the call's work ends on the
+    caller's stream).  XARM_RESET_OVERLAP=0 runs both resets on the caller's stream: same bits, through several hundred
+    resets per step."""
+    E = 20000
+
+    def run():
+        env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=13, step_coop_limit=1)
+        env.reset()
+        env.set_episode_steps(torch.arange(E, device=env.device) % 50)
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        rec = []
+        for _ in range(6):
+            obs, rew, done, info = env.step(torch.rand(E, 4, device="cuda", generator=gen) * 2 - 1)
+            rec.append(torch.cat([obs["observation"], obs["achieved_goal"], obs["desired_goal"], rew[:, None], done[:, None].float(),
+                                  info["terminal_observation"], env.get_state()], dim=1).clone())
+        env.close()
+        return torch.stack(rec)
+    on = run()
+    monkeypatch.setenv("XARM_RESET_OVERLAP", "0")
+    off = run()
+    assert torch.isfinite(on).all() and torch.equal(on, off)
+    assert int(on[:, :, 32].sum()) > 6 * 300          # done flags: the resets were really exercised
+
+
 def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
     """What a large PickAndPlace batch steps on by default - k_step_fast (the pad-free substep) with the hand-off of the
     envs that have an active finger-pad row to k_step_coop_list - against the plain k_step.  The fast substep is the plain

@@ -113,10 +113,9 @@ __global__ __launch_bounds__(WG) void k_step(KParams P, const float *__restrict_
                                              float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                              uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                              int *__restrict__ done_list, int *__restrict__ done_count,
-                                             int *__restrict__ stale_count, const int *__restrict__ list, const int *__restrict__ count) {
+                                             const int *__restrict__ list, const int *__restrict__ count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     const int64_t i_in = (int64_t)blockIdx.x * WG + threadIdx.x;
-    if (i_in == 0 && stale_count) *stale_count = 0; // counter of the step before last, consumed by its k_reset
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (count && n <= P.eject_coop_cap) return;     // k_step_coop_list's range
     if (i_in >= n) return;
@@ -163,10 +162,9 @@ __global__ __launch_bounds__(WG) void k_step_fast(KParams P, const float *__rest
                                                   float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                   uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                   int *__restrict__ done_list, int *__restrict__ done_count,
-                                                  int *__restrict__ stale_count, int *__restrict__ eject_list, int *__restrict__ eject_count) {
+                                                  int *__restrict__ eject_list, int *__restrict__ eject_count) {
     __shared__ float smem[FAST_LDS_FLOATS * WG];
     const int64_t e_in = (int64_t)blockIdx.x * WG + threadIdx.x;
-    if (e_in == 0 && stale_count) *stale_count = 0;
     if (e_in >= P.num_envs) return;
     FastLds lds{smem + threadIdx.x};
     xk::EnvState<float> s;
@@ -298,10 +296,8 @@ __global__ __launch_bounds__(WG) void k_step_coop(KParams P, const float *__rest
                                                   float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                   float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                   uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                  int *__restrict__ done_list, int *__restrict__ done_count,
-                                                  int *__restrict__ stale_count) {
+                                                  int *__restrict__ done_list, int *__restrict__ done_count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stale_count) *stale_count = 0;
     const int64_t e_raw = xcd_contiguous_block() * COOP_ENVS + threadIdx.x / xc::GL;
     const bool live = e_raw < P.num_envs;
     const int64_t e_in = live ? e_raw : P.num_envs - 1;
@@ -462,10 +458,8 @@ __global__ __launch_bounds__(WG) void k_reach_step(KParams P, const float *__res
                                                    float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                    float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                    uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                   int *__restrict__ done_list, int *__restrict__ done_count,
-                                                   int *__restrict__ stale_count) {
+                                                   int *__restrict__ done_list, int *__restrict__ done_count) {
     const int64_t e = (int64_t)blockIdx.x * WG + threadIdx.x;
-    if (e == 0 && stale_count) *stale_count = 0;
     if (e >= P.num_envs) return;
     xr::EnvState<float> s;
     reach_load(P, e, s);
@@ -512,9 +506,7 @@ __global__ __launch_bounds__(WG) void k_reach_step_coop(KParams P, const float *
                                                         float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                         float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                         uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                        int *__restrict__ done_list, int *__restrict__ done_count,
-                                                        int *__restrict__ stale_count) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stale_count) *stale_count = 0;
+                                                        int *__restrict__ done_list, int *__restrict__ done_count) {
     const int64_t e_raw = xcd_contiguous_block() * COOP_ENVS + threadIdx.x / xc::GL;
     const bool live = e_raw < P.num_envs;
     const int64_t e = live ? e_raw : P.num_envs - 1;
@@ -646,12 +638,10 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                int *__restrict__ done_list, int *__restrict__ done_count,
-                                                int *__restrict__ stale_count) {
+                                                int *__restrict__ done_list, int *__restrict__ done_count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
     const int arm = (int)(t & 1);
-    if (t == 0 && stale_count) *stale_count = 0;
     if (e_in >= P.num_envs) return;
     DevLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
@@ -782,12 +772,10 @@ __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restr
                                                  float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                  uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                 int *__restrict__ stale_count) {
+                                                 int *__restrict__ done_list, int *__restrict__ done_count) {
     __shared__ float smem[xh2::LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
     const int arm = (int)(t & 1);
-    if (t == 0 && stale_count) *stale_count = 0;
     if (e_in >= P.num_envs) return;
     DevLds lds{smem + threadIdx.x};
     xh2::Lane<float> L;
@@ -961,11 +949,10 @@ __global__ __launch_bounds__(WG) void k_st_step(KParams P, const float *__restri
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                int *__restrict__ stale_count, const int *__restrict__ order, uint8_t *__restrict__ key) {
+                                                const int *__restrict__ order, uint8_t *__restrict__ key) {
     __shared__ float smem[xs::LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, slot = t >> 1;
     const int arm = (int)(t & 1);
-    if (t == 0 && stale_count) *stale_count = 0;
     if (slot >= P.num_envs) return;
     const int64_t e_in = order ? (int64_t)order[slot] : slot;
     DevLds lds{smem + threadIdx.x};
@@ -1034,7 +1021,9 @@ struct xarm_handle {
     xarm_config cfg;
     KParams kp;
     int *done_list;   // [E]
-    int *done_count;  // [2] ping-pong counters
+    int *counters;    // [3 + 2 * NCLS], zeroed by ONE memset at the start of every step call (no host-side state: a captured
+                      // step can be replayed): done_count = +0, eject_count = +1 (2), class_hist = +3
+    int *done_count;  // [1] episodes that ended in this call (list A)
     int *mask_count;  // [1]
     int coop_step_limit; // PickAndPlace: batches of at most this many envs step on k_step_coop
     int fast_pipeline;   // PickAndPlace, larger batches: k_step_fast + hand-off of the envs with finger-pad rows (1) or k_step (0)
@@ -1050,7 +1039,6 @@ struct xarm_handle {
     uint8_t *class_key;  // [E] row-set class of each env's last substep
     int *class_hist;     // [2 * NCLS] histogram, then the per-class arrival counters
     int *class_order;    // [E] slot -> env
-    uint64_t step_index;
     char err[512];
     // timing
     int timing;
@@ -1217,12 +1205,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.rcfg.reward_type = cfg->reward_type;
     hipError_t e1 = hipMalloc(&h->kp.state, sizeof(float) * h->kp.state_dim * stride);
     hipError_t e2 = hipMalloc(&h->done_list, sizeof(int) * stride);
-    hipError_t e3 = hipMalloc(&h->done_count, sizeof(int) * 2);
+    hipError_t e3 = hipMalloc(&h->counters, sizeof(int) * (3 + 2 * xs::NCLS));
+    h->done_count = h->counters; h->eject_count = h->counters + 1; h->class_hist = h->counters + 3;
     hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
     if (e4 == hipSuccess && h->fast_pipeline) {
         e4 = hipMalloc(&h->eject_list, sizeof(int) * stride);
-        if (e4 == hipSuccess) e4 = hipMalloc(&h->eject_count, sizeof(int) * 2);
-        if (e4 == hipSuccess) e4 = hipMemset(h->eject_count, 0, sizeof(int) * 2);
         if (e4 == hipSuccess) e4 = hipMalloc(&h->done_list_b, sizeof(int) * stride);
         const char *ev = getenv("XARM_RESET_OVERLAP");
         if (e4 == hipSuccess && cfg->auto_reset && !(ev && *ev && atoi(ev) == 0)) {
@@ -1236,7 +1223,6 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         const char *ev = getenv("XARM_ST_CLASS_ORDER");
         if (!(ev && *ev && atoi(ev) == 0)) {
             e4 = hipMalloc(&h->class_key, stride);
-            if (e4 == hipSuccess) e4 = hipMalloc(&h->class_hist, sizeof(int) * 2 * xs::NCLS);
             if (e4 == hipSuccess) e4 = hipMalloc(&h->class_order, sizeof(int) * stride);
             if (e4 == hipSuccess) e4 = hipMemset(h->class_key, 0, stride);
         }
@@ -1247,7 +1233,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         return XARM_E_HIP;
     }
     hipMemset(h->kp.state, 0, sizeof(float) * h->kp.state_dim * stride);
-    hipMemset(h->done_count, 0, sizeof(int) * 2);
+    hipMemset(h->counters, 0, sizeof(int) * (3 + 2 * xs::NCLS));
     hipMemset(h->mask_count, 0, sizeof(int));
     if (reach) k_reach_init<<<dim3((unsigned)(stride / WG)), dim3(WG)>>>(h->kp);
     else if (handover2) k_ho2_init<<<dim3((unsigned)(2 * stride / WG)), dim3(WG)>>>(h->kp);
@@ -1272,16 +1258,14 @@ int xarm_destroy(xarm_handle *h) {
         for (int i = 0; i < xarm_handle::NEV; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); hipEventDestroy(h->ev2[i]); }
     if (h->kp.state) hipFree(h->kp.state);
     if (h->done_list) hipFree(h->done_list);
-    if (h->done_count) hipFree(h->done_count);
+    if (h->counters) hipFree(h->counters);
     if (h->mask_count) hipFree(h->mask_count);
     if (h->eject_list) hipFree(h->eject_list);
-    if (h->eject_count) hipFree(h->eject_count);
     if (h->done_list_b) hipFree(h->done_list_b);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->side) hipStreamDestroy(h->side);
     if (h->class_key) hipFree(h->class_key);
-    if (h->class_hist) hipFree(h->class_hist);
     if (h->class_order) hipFree(h->class_order);
     delete h;
     return XARM_OK;
@@ -1332,7 +1316,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         return fail(h, XARM_E_INVALID, "%s", "xarm_step: null buffer");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(h->kp.stride / WG);
-    int *cnt = h->done_count + (h->step_index & 1), *stale = h->done_count + ((h->step_index + 1) & 1);
+    int *cnt = h->done_count;
     const bool timed = h->timing && h->ev_created;
     bool pipelined = false;
     const bool overlap = h->reset_overlap && h->kp.auto_reset;
@@ -1343,47 +1327,47 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (h->kp.auto_reset == XARM_AUTO_RESET_LAZY) {
         k_step_lazy<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev);
         if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
-        h->step_index++;
         HIPCHK(h, hipGetLastError());
         return XARM_OK;
     }
+    // the call's device-side counters (ended episodes, hand-offs, class histogram): zeroed here, in stream order - the
+    // handle keeps no host-side per-step state, so a captured step call replays correctly
+    HIPCHK(h, hipMemsetAsync(h->counters, 0, sizeof(int) * ((stack && h->class_key) ? 3 + 2 * xs::NCLS : (h->fast_pipeline ? 3 : 1)), st));
     if (stack) {
         if (h->class_key) {
-            HIPCHK(h, hipMemsetAsync(h->class_hist, 0, sizeof(int) * 2 * xs::NCLS, st));
             const unsigned cg = (unsigned)((h->kp.num_envs + 255) / 256);
             k_class_hist<<<dim3(cg), dim3(256), 0, st>>>(h->class_key, h->kp.num_envs, h->class_hist);
             k_class_place<<<dim3(cg), dim3(256), 0, st>>>(h->class_key, h->kp.num_envs, h->class_hist, h->class_hist + xs::NCLS, h->class_order, WG / 2);
         }
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                       terminal_obs_dev, h->done_list, cnt, stale, h->class_order, h->class_key);
+                                                       terminal_obs_dev, h->done_list, cnt, h->class_order, h->class_key);
     }
     else if (handover && h->cfg.num_obj == 2)
         k_ho2_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                        terminal_obs_dev, h->done_list, cnt, stale);
+                                                        terminal_obs_dev, h->done_list, cnt);
     else if (handover && h->kp.hcfg.use_stand)
         k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                           success_dev, terminal_obs_dev, h->done_list, cnt, stale);
+                                                                           success_dev, terminal_obs_dev, h->done_list, cnt);
     else if (handover)
         k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                      success_dev, terminal_obs_dev, h->done_list, cnt, stale);
+                                                                      success_dev, terminal_obs_dev, h->done_list, cnt);
     else if (reach && h->kp.num_envs <= (int64_t)h->coop_step_limit)
         k_reach_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, stale);
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt);
     else if (reach)
         k_reach_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                      terminal_obs_dev, h->done_list, cnt, stale);
+                                                      terminal_obs_dev, h->done_list, cnt);
     else if (h->kp.num_envs <= (int64_t)h->coop_step_limit)
         k_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, stale);
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt);
     else if (h->fast_pipeline) {
         // every env on the pad-free fast step; the ones with an active finger-pad row are handed off, untouched, to the
         // cooperative kernel (lists of at most eject_coop_cap envs) or to k_step (longer lists) - both launched, the one
         // out of its range exits at once (the count lives on the device).  Episodes that end in the hand-off go to a
         // list of their own (done_list_b): the reset of the ~98 % that ended in k_step_fast need not wait for it.
         pipelined = true;
-        HIPCHK(h, hipMemsetAsync(h->eject_count, 0, sizeof(int) * 2, st));
         k_step_fast<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                     terminal_obs_dev, h->done_list, cnt, stale, h->eject_list, h->eject_count);
+                                                     terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
         if (overlap) {
             // a reset is six sequential ticks of latency on a few hundred wavefronts (2.9 ms), the hand-off 0.55 ms on a
             // few hundred others: started now on the side stream, the first reset overlaps the hand-off, and the second -
@@ -1401,10 +1385,10 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                            terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
         if (h->kp.num_envs > cap)
             k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                    terminal_obs_dev, list_b, cnt_b, nullptr, h->eject_list, h->eject_count);
+                                                    terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
     } else
         k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                terminal_obs_dev, h->done_list, cnt, stale, nullptr, nullptr);
+                                                terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
     if (h->kp.auto_reset && pipelined && overlap) {
         launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
@@ -1416,7 +1400,6 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         else launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);
     }
     if (timed) { HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
-    h->step_index++;
     HIPCHK(h, hipGetLastError());
     return XARM_OK;
 }

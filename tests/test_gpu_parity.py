@@ -316,6 +316,44 @@ def test_world_size_invariance_at_the_baseline_split(gx):
     assert float(err.median()) < 1e-4 and bool(torch.equal(dflt[0][:, 31:34], full[0][off:off + n, 31:34]))
 
 
+@pytest.mark.parametrize("env_id,E,A", [("XarmPDPickAndPlace-v0", 16384, 4), ("XarmReach-v0", 512, 4), ("XarmPDStackTower-v0", 512, 8)])
+def test_a_captured_step_replays_like_eager_steps(gx, env_id, E, A):
+    """xarm_step keeps no host-side per-step state (its device counters are zeroed by a memset inside the call), forks and
+    joins its side stream inside the call: one step captured into a HIP graph (torch.cuda.graph) and replayed with new
+    actions gives the bits of eager steps - incl. the auto-resets, the hand-off lists and StackTower's class order"""
+    def run(capture):
+        env = gx.make(env_id, num_envs=E, seed=1)
+        env.reset()
+        env.set_episode_steps(torch.arange(E, device=env.device) % env._max_episode_steps)
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        acts = [torch.rand(E, A, device="cuda", generator=gen) * 2 - 1 for _ in range(6)]
+        a = acts[0].clone()
+        outs = []
+        if capture:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                env.step(a)                       # first call outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                obs, rew, done, info = env.step(a)
+            for k in range(1, 6):
+                a.copy_(acts[k])
+                graph.replay()
+                outs.append(torch.cat([obs["observation"], rew[:, None], done[:, None].float(), env.get_state()], 1).clone())
+        else:
+            env.step(a)
+            for k in range(1, 6):
+                obs, rew, done, info = env.step(acts[k])
+                outs.append(torch.cat([obs["observation"], rew[:, None], done[:, None].float(), env.get_state()], 1).clone())
+        torch.cuda.synchronize()
+        env.close()
+        return torch.stack(outs)
+    eager, replay = run(False), run(True)
+    assert torch.isfinite(eager).all() and torch.equal(eager, replay)
+
+
 def test_overlapped_reset_changes_nothing_but_the_time(gx, monkeypatch):
     """A pipelined PickAndPlace step resets the episodes that ended in k_step_fast on a side stream while the hand-off still
     runs, and those that ended in the hand-off after it (two lists, two launches, joined before the call's work ends on the

@@ -50,6 +50,24 @@ def build(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+def build_example(verbose=True):
+    """examples/abi_step_loop: a plain-C host program on include/xarm_hip.h (gcc, no torch, no Python)."""
+    root = os.path.dirname(HERE)
+    src, out = os.path.join(root, "examples", "abi_step_loop.c"), os.path.join(root, "examples", "abi_step_loop")
+    if not os.path.exists(src):
+        return None
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(root, "include", "xarm_hip.h"))):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O2", "-std=c11", "-I", os.path.join(root, "include"), "-I", os.path.join(rocm, "include"), src,
+           "-L", CSRC, "-lxarm_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/../gym_xarm_amd/csrc", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

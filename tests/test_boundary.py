@@ -122,3 +122,15 @@ def test_missing_extension_is_an_error(tmp_path):
     from gym_xarm_amd import _native
     with pytest.raises(_native.XarmNativeError, match="not found"):
         _native.load(str(tmp_path / "libxarm_hip.so"))
+
+
+@pytest.mark.gpu
+def test_gpu_plain_c_host_program_on_the_abi():
+    """examples/abi_step_loop.c: a gcc-built plain-C program that binds include/xarm_hip.h directly (hipMalloc'd buffers, its
+    own stream, no torch, no Python) resets and steps 2 048 envs with auto-reset and exits 0 with finite observations"""
+    import subprocess
+    from gym_xarm_amd import build as b
+    exe = b.build_example(verbose=False)
+    out = subprocess.run([exe, "2048", "30"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "2048 envs x 30 steps" in out.stdout and "non-finite 0" in out.stdout and "obs_dim 24" in out.stdout

@@ -58,11 +58,16 @@ class SB3VecEnv:
         done = _np(done_t).astype(bool)
         succ = _np(info_t["is_success"]).astype(np.float32)
         trunc = _np(info_t["TimeLimit.truncated"]).astype(bool)
-        infos = [{"is_success": float(succ[i])} for i in range(self.num_envs)]
+        # 65 536 dicts per call: plain Python floats from one tolist() per key (a numpy scalar conversion per env is ~5x slower)
+        infos = [{"is_success": x} for x in succ.tolist()]
         extra = {k: _np(v) for k, v in info_t.items() if k not in ("is_success", "TimeLimit.truncated", "terminal_observation") and torch.is_tensor(v)}
         for k, v in extra.items():
-            for i in range(self.num_envs):
-                infos[i][k] = v[i].item() if v[i].ndim == 0 else v[i]
+            if v.ndim == 1:
+                for d, x in zip(infos, v.tolist()):
+                    d[k] = x
+            else:
+                for d, x in zip(infos, v):
+                    d[k] = x
         idx = np.nonzero(done)[0]
         if idx.size:
             term = _np(info_t["terminal_observation"][torch.from_numpy(idx).to(info_t["terminal_observation"].device)])

@@ -405,6 +405,9 @@ def main():
         reset_traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (reset_kernel_key, E))
         reset_entry = {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms, "resets_per_call": resets_per_call,
                        "algorithmic_bytes_per_launch": reset_algo, "traffic": reset_traffic}
+        if kernel_name == "k_step_fast":
+            reset_entry["note"] = ("two launches per call: the episodes that ended in k_step_fast are reset on a side stream while the hand-off "
+                                   "runs, those that ended in the hand-off after it; avg_ms = what is left of both after the hand-off (DESIGN.md 4b)")
         if reset_ms > 0:
             reset_entry["achieved_GBs"] = reset_algo / (reset_ms * 1e-3) / 1e9
             reset_entry["frac"] = reset_entry["achieved_GBs"] / HBM_PEAK_GBS

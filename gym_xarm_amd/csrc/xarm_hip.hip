@@ -1370,8 +1370,9 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                      terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
         if (overlap) {
             // a reset is six sequential ticks of latency on a few hundred wavefronts (2.9 ms), the hand-off 0.55 ms on a
-            // few hundred others: started now on the side stream, the first reset overlaps the hand-off, and the second -
-            // a handful of envs, whose slowest wavefront is rarely a slow one - is what the call waits for
+            // few hundred others: started now on the side stream, the first reset overlaps the hand-off.  The call still
+            // waits for the second one - a few dozen envs, but the ones with a finger contact, whose reset carries the pad
+            // rows through the homing ticks (worth 0.16 ms per call at 16 384 envs, nothing at 65 536)
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
             launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->side);

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libxarm_hip.so")
 SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h",
-           "xarm_stack_core.h", "xarm_coop_core.h", "xarm_reach_coop_core.h"]
+           "xarm_stack_core.h", "xarm_coop_core.h", "xarm_reach_coop_core.h", "xarm_handover_coop_core.h"]
 # -fno-slp-vectorize: LLVM's SLP pass pairs the scalar fp32 ops of the unrolled solver into v_pk_* instructions,
 # which need even-aligned register pairs; in this 400-live-value kernel that costs ~30 % extra v_mov and pushes
 # 1.3 KB/lane into scratch.  Without it the step kernel needs 28 B/lane of scratch and 18 % fewer instructions.

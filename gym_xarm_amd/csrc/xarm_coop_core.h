@@ -220,7 +220,7 @@ template <typename T> XARM_HD V3<T> tdir(int a) { return mk<T>(a == 2 ? (T)1 : (
 // Slots 0 and 1 (table rows, single-joint rows) exist in every instantiation and are therefore built by ONE piece of
 // code that runs before the row set is chosen: whatever the neighbours in the wavefront need, these values and the
 // sweep's single-rounding operations on them are the same bits.
-template <typename T>
+template <typename T, typename Scene = xk::PnpScene>
 XARM_HD void lane_rows_base(const Setup<T> &S, int l, T (&R)[R_N]) {
     const T inf = (T)3.0e38;
 #pragma unroll
@@ -250,8 +250,8 @@ XARM_HD void lane_rows_base(const Setup<T> &S, int l, T (&R)[R_N]) {
         for (int d = 0; d < 9; d++) { vt = l == d ? S.m_vt[d] : vt; ju += R[R_J1 + d] * S.dq[d]; }
         vt = l == 9 ? S.lf_vt[0][0] : (l == 10 ? S.lf_vt[0][1] : (l == 11 ? S.lf_vt[1][0] : (l == 12 ? S.lf_vt[1][1] : (l == 13 ? S.g_vt : vt))));
         R[R_G + 1] = l < NA1 ? vt - ju : (T)0;
-        const T m_hi_arm = (T)(xm::ARM_MOTOR_FORCE * xk::PnpScene::TIME_STEP), m_hi_fin = (T)(xk::PnpScene::FINGER_MOTOR_FORCE * xk::PnpScene::TIME_STEP);
-        const T g_hi = (T)(xm::GEAR_MAX_FORCE * xk::PnpScene::TIME_STEP);
+        const T m_hi_arm = (T)(xm::ARM_MOTOR_FORCE * Scene::TIME_STEP), m_hi_fin = (T)(Scene::FINGER_MOTOR_FORCE * Scene::TIME_STEP);
+        const T g_hi = (T)(xm::GEAR_MAX_FORCE * Scene::TIME_STEP);
         const T hi = l < 7 ? m_hi_arm : (l < 9 ? m_hi_fin : (l < 13 ? inf : (l == 13 ? g_hi : (T)0)));
         R[R_HI1] = hi;
         R[R_LO1] = (l >= 9 && l < 13) ? (T)0 : -hi;
@@ -321,9 +321,9 @@ template <typename T> XARM_HD void arm_row_B(const Setup<T> &S, int r, T (&B)[9]
         else B[d] = S.la_sg[r - NA1] * S.Minv[symi(d, r - NA1)];
     }
 }
-template <typename T>
+template <typename T, typename Scene = xk::PnpScene>
 XARM_HD void lane_delassus_base(const Setup<T> &S, int l, const T (&R)[R_N], T (&nA0)[C0_N], T (&nA1)[C1_N], T (&invd)[4]) {
-    const T imb = (T)(1.0 / xk::PnpScene::OBJ_MASS);
+    const T imb = (T)(1.0 / Scene::OBJ_MASS);
 #pragma unroll
     for (int k = 0; k < 4; k++) invd[k] = (T)0;
     T diag0 = (T)1, diag1 = (T)1;
@@ -356,9 +356,9 @@ XARM_HD void lane_delassus_base(const Setup<T> &S, int l, const T (&R)[R_N], T (
     invd[1] = l < NA1 ? (T)1 / diag1 : (T)0;
 }
 // the entries that exist only with pad rows (slot 2) and / or arm-limit rows (slot 3)
-template <typename T, bool PAD, bool LA>
+template <typename T, bool PAD, bool LA, typename Scene = xk::PnpScene>
 XARM_HD void lane_delassus_extra(const Setup<T> &S, int l, const T (&R)[R_N], T (&nA1)[C1_N], T (&nA2)[C2_N], T (&nA3)[C1_N], T (&invd)[4]) {
-    const T imb = (T)(1.0 / xk::PnpScene::OBJ_MASS);
+    const T imb = (T)(1.0 / Scene::OBJ_MASS);
     T diag3 = (T)1;
     bool act3 = false;
     if (PAD) {
@@ -404,10 +404,10 @@ template <typename T> struct Sweep {
 // Columns of A that belong to the pad rows.  M^-1 J_r^T of a pad row is expensive (full 9x9 product), so the lane
 // that owns row r forms it once for its own row and the row is then handed round by DPP broadcast: every lane dots
 // it with the Jacobians of the rows it owns.  padw[p]: pad p has a live row somewhere in the wavefront.
-template <typename T, bool LA>
-XARM_HD void pad_columns(const Grp &G, const Setup<T> &S, const LV<T> (&J)[R_G], LV<T> cfm, Sweep<T> &W, const bool (&padw)[NP]) {
-    const T imb = (T)(1.0 / xk::PnpScene::OBJ_MASS);
-    LV<T> Ba[9], Bb[6];
+// M^-1 J_r^T of the pad row each lane owns: joint part Ba (9), object part Bb (linear 3, angular 3)
+template <typename T, typename Scene = xk::PnpScene>
+XARM_HD void pad_minv_jt(const Setup<T> &S, const LV<T> (&J)[R_G], LV<T> (&Ba)[9], LV<T> (&Bb)[6]) {
+    const T imb = (T)(1.0 / Scene::OBJ_MASS);
 #pragma unroll
     for (int q = 0; q < 9; q++) {
         LV<T> s = lv_scale(J[R_J2A + 0], S.Minv[symi(q, 0)]);
@@ -420,6 +420,11 @@ XARM_HD void pad_columns(const Grp &G, const Setup<T> &S, const LV<T> (&J)[R_G],
     Bb[3] = lv_fmas(J[R_J2B + 5], S.Iinv[2], lv_fmas(J[R_J2B + 4], S.Iinv[1], lv_scale(J[R_J2B + 3], S.Iinv[0])));
     Bb[4] = lv_fmas(J[R_J2B + 5], S.Iinv[4], lv_fmas(J[R_J2B + 4], S.Iinv[3], lv_scale(J[R_J2B + 3], S.Iinv[1])));
     Bb[5] = lv_fmas(J[R_J2B + 5], S.Iinv[5], lv_fmas(J[R_J2B + 4], S.Iinv[4], lv_scale(J[R_J2B + 3], S.Iinv[2])));
+}
+template <typename T, bool LA, typename Scene = xk::PnpScene>
+XARM_HD void pad_columns(const Grp &G, const Setup<T> &S, const LV<T> (&J)[R_G], LV<T> cfm, Sweep<T> &W, const bool (&padw)[NP]) {
+    LV<T> Ba[9], Bb[6];
+    pad_minv_jt<T, Scene>(S, J, Ba, Bb);
 #define XC_PAD_COL(r)                                                                                        \
     if (padw[(r) / 3]) {                                                                                     \
         LV<T> ca[9], cb[6];                                                                                  \
@@ -632,12 +637,12 @@ template <typename T> XARM_HD ArmLane<T> arm_lane_consts(const Grp &G) {
     return C;
 }
 
-template <typename T, typename Lds>
-XARM_HD void arm_dynamics_coop(const Grp &G, const ArmLane<T> &C, const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, xk::ArmDyn<T> &A) {
+template <typename T, typename Lds, typename Scene = xk::PnpScene>
+XARM_HD void arm_dynamics_coop(const Grp &G, const ArmLane<T> &C, const T (&q_in)[9], const T (&qd_in)[9], const T dt, Lds lds, xk::ArmDyn<T> &A, const int arm = 0) {
     using xk::SV; using xk::RBI; using xk::Frame;
     // ---- the chain, walked by every lane; lane i captures body i's frame / spatial velocity / acceleration / joint rate
     SV<T> S[7];
-    Frame<T> f = xk::frame_identity<T>();
+    Frame<T> f = Scene::template base_frame<T>(arm);
     SV<T> vel, acc;
     vel.w = mk<T>(0, 0, 0); vel.v = mk<T>(0, 0, 0);
     acc.w = mk<T>(0, 0, 0); acc.v = mk<T>(0, 0, (T)xm::GRAVITY);
@@ -807,12 +812,11 @@ XARM_HD void arm_dynamics_coop(const Grp &G, const ArmLane<T> &C, const T (&q_in
 // ---------------------------------------------------------------------------------------------
 // collision + row constants of a substep: same arithmetic as the first half of xk::substep, minus the
 // operational-space K blocks (the Delassus rows replace them)
-template <typename T, typename Lds>
-XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, Setup<T> &S) {
-    using Scene = xk::PnpScene;
+template <typename T, typename Lds, typename Scene = xk::PnpScene>
+XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, Setup<T> &S, const int arm = 0) {
     const T idt = (T)1 / dt;
     xk::ArmDyn<T> AD;
-    arm_dynamics_coop<T, Lds>(G, C, st.q, st.qd, dt, lds, AD);
+    arm_dynamics_coop<T, Lds, Scene>(G, C, st.q, st.qd, dt, lds, AD, arm);
 #pragma unroll
     for (int k = 0; k < 45; k++) S.Minv[k] = AD.Minv[k];
 #pragma unroll
@@ -887,6 +891,28 @@ XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, c
             }
             cnt += act ? 1 : 0;
         }
+        if constexpr (Scene::HAS_STAND) {
+            // the static stand under the goal: up to four more support points (ids 8..11, no warm start) after the corners
+            V3<T> sp[4];
+            T sd[4];
+            Scene::template stand_points<T>(st.goal, cb, b0, b1, b2, sp, sd);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const T dist = sd[v];
+                const bool act = dist < (T)xm::SOLVER_MARGIN && dist > (T)Scene::STAND_MIN_GAP && cnt < NTS;
+                const V3<T> r = sp[v] - cb;
+                const T vt = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist * idt : -dist * idt;
+#pragma unroll
+                for (int s = 0; s < NTS; s++) {
+                    const bool put = act && cnt == s;
+                    S.tr[s] = xk::selv(put, r, S.tr[s]);
+                    S.tvt[s] = put ? vt : S.tvt[s];
+                    S.tl0[s] = put ? (T)0 : S.tl0[s];
+                    S.tid[s] = put ? 8 + v : S.tid[s];
+                }
+                cnt += act ? 1 : 0;
+            }
+        }
     }
     // (M) motors, (L) limits, (G) gear: targets
 #pragma unroll
@@ -960,13 +986,13 @@ XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, c
 }
 
 // rows -> Sweep (host: gather the 16 per-lane evaluations); base = slots 0 and 1, before the row set is chosen
-template <typename T>
+template <typename T, typename Scene = xk::PnpScene>
 XARM_HD void build_base(const Grp &G, const Setup<T> &S, Sweep<T> &W, LV<T> (&J)[R_G]) {
     XC_LANES {
         const int l = lane_of(G, i_);
         T R[R_N], a0[C0_N], a1[C1_N], iv[4];
-        lane_rows_base<T>(S, l, R);
-        lane_delassus_base<T>(S, l, R, a0, a1, iv);
+        lane_rows_base<T, Scene>(S, l, R);
+        lane_delassus_base<T, Scene>(S, l, R, a0, a1, iv);
 #pragma unroll
         for (int k = 0; k < R_J2A; k++) J[k].v[i_] = R[k];
 #pragma unroll
@@ -978,7 +1004,7 @@ XARM_HD void build_base(const Grp &G, const Setup<T> &S, Sweep<T> &W, LV<T> (&J)
         for (int k = 0; k < NA1; k++) W.nA1[C1_A + k].v[i_] = a1[C1_A + k];
     }
 }
-template <typename T, typename Lds, bool PAD, bool LA>
+template <typename T, typename Lds, bool PAD, bool LA, typename Scene = xk::PnpScene>
 XARM_HD void build_extra(const Grp &G, const Setup<T> &S, Lds lds, Sweep<T> &W, LV<T> (&J)[R_G], LV<T> &cfm) {
     XC_LANES {
         const int l = lane_of(G, i_);
@@ -992,7 +1018,7 @@ XARM_HD void build_extra(const Grp &G, const Setup<T> &S, Lds lds, Sweep<T> &W, 
 #pragma unroll
         for (int k = 0; k < 4; k++) iv[k] = (T)0;
         lane_rows_extra<T, Lds, PAD, LA>(S, lds, l, R);
-        lane_delassus_extra<T, PAD, LA>(S, l, R, a1, a2, a3, iv);
+        lane_delassus_extra<T, PAD, LA, Scene>(S, l, R, a1, a2, a3, iv);
 #pragma unroll
         for (int k = R_J2A; k < R_G; k++) J[k].v[i_] = R[k];
 #pragma unroll

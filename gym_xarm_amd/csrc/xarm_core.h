@@ -610,7 +610,6 @@ XARM_HD void arm_dynamics(const T (&q_in)[9], const T (&qd_in)[9], const T dt, L
 // with one such lane sweeps the pad blocks for all 64 (k_step 1.88 ms against 0.74 ms for a contact-free batch).
 template <typename T, typename Lds, typename Scene = PnpScene, typename Xchg = NoXchg, bool FAST = false>
 XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, const int arm = 0, const Xchg xchg = Xchg()) {
-    static_assert(!FAST || Scene::NARMS == 1, "the pad-free fast substep exists for the single-arm scene");
     const T idt = (T)1 / dt;
     ArmDyn<T> AD;
     arm_dynamics<T, Lds, Scene, !FAST, !FAST>(st.q, st.qd, dt, lds, arm, AD);
@@ -925,7 +924,7 @@ XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 }
             }
         }
-        if (Scene::NARMS == 2) {
+        if (Scene::NARMS == 2 && !FAST) {
             // the object also receives the warm-start impulses of the other arm's pads
             const V3<T> dv = vb - vb_pre, dw = wb - wb_pre;
             vb = vb + mk<T>(xchg.partner(dv.x), xchg.partner(dv.y), xchg.partner(dv.z));
@@ -939,7 +938,7 @@ XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
 
     // two arms: the finger phases of the two arms commute unless both arms touch the object; `seq` is wave-uniform
     bool other_any = false, seq = false;
-    if (Scene::NARMS == 2) {
+    if (Scene::NARMS == 2 && !FAST) {   // (the fast substep has no pad rows: the arms never interact)
         other_any = xchg.partner(pad_any ? (T)1 : (T)0) != (T)0;
         seq = XARM_ANY_X(pad_any && other_any);
     }
@@ -1141,7 +1140,7 @@ XARM_HD bool substep(EnvState<T> &st, const T (&qt)[9], const T dt, Lds lds, con
                 dq8 += lds[LDS_T + 8 * 6 + k] * wtot[k];
             }
         }
-        if (Scene::NARMS == 2) {
+        if (Scene::NARMS == 2 && !FAST) {
             if (ph == 0) {
                 const V3<T> f0 = mk<T>(xchg.from0(vb.x), xchg.from0(vb.y), xchg.from0(vb.z)), g0 = mk<T>(xchg.from0(wb.x), xchg.from0(wb.y), xchg.from0(wb.z));
                 const V3<T> pv = mk<T>(xchg.partner(vb.x), xchg.partner(vb.y), xchg.partner(vb.z)), pw = mk<T>(xchg.partner(wb.x), xchg.partner(wb.y), xchg.partner(wb.z));

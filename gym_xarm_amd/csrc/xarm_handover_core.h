@@ -217,7 +217,6 @@ XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds
     L.st.episode = (T)episode;
 }
 
-// act = this arm's 4 action entries (:249-256)
 // staged dense reward (:184-199), evaluated identically by both lanes of the env: grip_k = hand COM of arm k -
 // eef2grip_offset (this lane's from arm_obs, the other arm's from its lane), if_k = the grasp flags _set_action read
 // before the step's simulation (:263-264 = st.mug).  The reference's last branch (only arm 2 holds the object) reads
@@ -238,10 +237,11 @@ XARM_HD T dense_reward(const Lane<T> &L, int arm, T d_og, Xchg x) {
     return ((T)2 + (T)0.25 * ((T)1 - xk::xtanh(d_og))) * k;
 }
 
-template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
-XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
+// XarmHandover.step up to the simulation (:128-130, _set_action :244-297): clip, Cartesian target, IK, finger target, friction
+// toggle, stick clamp.  Shared by every mapping of the step (lane pair, pad-free fast lane pair, cooperative rows).
+template <typename T> XARM_HD void step_begin(Lane<T> &L, int arm, const T (&act)[4], T (&qt)[9]) {
     L.st.steps += (T)1;
-    T a[4], qt[9];
+    T a[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) a[k] = clampT(act[k], (T)-1, (T)1);
     const V3<T> cur = eef_pos(L, arm);
@@ -268,14 +268,44 @@ XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &
 #pragma unroll
         for (int k = 0; k < 3; k++) { L.st.bv[k] = (T)0; L.st.bw[k] = (T)0; }
     }
-#pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
+}
+// ... and after it: reward (:164-199), success (:395-402), done (success or the 100-step limit)
+template <typename T, typename Xchg>
+XARM_HD void step_end(const Lane<T> &L, int arm, T &reward, bool &done, bool &success, Xchg x, int reward_type) {
     const T dx = L.st.bp[0] - L.st.goal[0], dy = L.st.bp[1] - L.st.goal[1], dz = L.st.bp[2] - L.st.goal[2];
     const T dist = xk::xsqrt(dx * dx + dy * dy + dz * dz);
     success = dist < (T)xm::HO_DISTANCE_THRESHOLD;
     reward = dist > (T)xm::HO_DISTANCE_THRESHOLD ? (T)-1 : (T)0;   // -sum(d > thr) for one object (:177-181)
     if (reward_type == 1) reward = dense_reward<T, Xchg>(L, arm, dist, x);
     done = success || ((int)L.st.steps == xm::HO_MAX_EPISODE_STEPS);
+}
+
+// act = this arm's 4 action entries (:249-256)
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
+XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
+    T qt[9];
+    step_begin(L, arm, act, qt);
+#pragma unroll 1
+    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
+    step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
+}
+
+// The same step on the pad-free fast substep (xk::substep<.., FAST>: no finger-pad rows, nothing of the arm in LDS, no
+// exchange inside the sweep - without pad rows the two arms never interact and the object-only rows are computed
+// identically by both lanes).  Returns false when a finger-pad row of EITHER arm was active in any of the 15 ticks: the
+// outputs are then meaningless and the caller must not store them (the environment is stepped again, from its untouched
+// state, by the cooperative kernel: xarm_handover_coop_core.h).
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
+XARM_HD bool lane_step_fast(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
+    T qt[9];
+    step_begin(L, arm, act, qt);
+    bool pad = false;
+#pragma unroll 1
+    for (int k = 0; k < xm::HO_N_TICKS; k++)
+        pad = xk::substep<T, Lds, Scene, Xchg, true>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x) || pad;
+    step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
+    const bool other = x.partner(pad ? (T)1 : (T)0) != (T)0;
+    return !(pad || other);
 }
 
 } // namespace xh

@@ -25,6 +25,7 @@
 #include "xarm_handover2_core.h"
 #include "xarm_stack_core.h"
 #include "xarm_coop_core.h"
+#include "xarm_handover_coop_core.h"
 #include "xarm_reach_coop_core.h"
 
 namespace {
@@ -633,16 +634,22 @@ __global__ __launch_bounds__(WG) void k_ho_init(KParams P) {
     xh::lane_init<float>(P.hcfg, e, L);
     ho_store(P, e, arm, L);
 }
+// XarmHandover.step for every env (list == null) or for the envs list[0 .. *count) (the hand-off of k_ho_step_fast when it
+// is too long for the cooperative kernel)
 template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
-                                                int *__restrict__ done_list, int *__restrict__ done_count) {
+                                                int *__restrict__ done_list, int *__restrict__ done_count,
+                                                const int *__restrict__ list, const int *__restrict__ count) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
-    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i_in = t >> 1;
     const int arm = (int)(t & 1);
-    if (e_in >= P.num_envs) return;
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (count && n <= P.eject_coop_cap) return;     // k_ho_step_coop_list's range
+    if (i_in >= n) return;
+    const int64_t e_in = list ? (int64_t)list[i_in] : i_in;
     DevLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
     ho_load(P, e_in, arm, L);
@@ -672,6 +679,7 @@ __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restric
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
     const int arm = (int)(t & 1);
     const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n <= P.coop_limit) return;                  // k_ho_reset_coop's range
     if (i >= n) return;
     const int64_t e_in = list ? (int64_t)list[i] : i;
     DevLds lds{smem + threadIdx.x};
@@ -687,6 +695,145 @@ __global__ void k_ho_compute_reward(const float *__restrict__ ag, const float *_
     if (i >= n) return;
     const float dx = ag[i * 3] - g[i * 3], dy = ag[i * 3 + 1] - g[i * 3 + 1], dz = ag[i * 3 + 2] - g[i * 3 + 2];
     out[i] = sqrtf(dx * dx + dy * dy + dz * dz) > (float)xm::HO_DISTANCE_THRESHOLD ? -1.f : 0.f;
+}
+
+// The fast Handover step: XarmHandover.step on the pad-free lane-pair substep for every env (xh::lane_step_fast).  An env none
+// of whose finger pads comes within the solver margin of the stick during the step is finished here; an env with an active
+// pad row on either arm stores NOTHING and is appended to eject_list: it is stepped again, from its untouched state, by
+// k_ho_step_coop_list (or k_ho_step when the list is long).  Why: a wavefront of k_ho_step with ONE such lane sweeps the pad
+// blocks for all 32 of its envs (2.3 ms against 0.96 ms for a contact-free batch, tools/ho_time.py).  Only the support-slot
+// columns live in LDS.
+template <typename Scene>
+__global__ __launch_bounds__(WG) void k_ho_step_fast(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                     float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                     float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                     uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                     int *__restrict__ done_list, int *__restrict__ done_count,
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count) {
+    __shared__ float smem[FAST_LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int arm = (int)(t & 1);
+    if (e_in >= P.num_envs) return;
+    FastLds lds{smem + threadIdx.x};
+    xh::Lane<float> L;
+    ho_load(P, e_in, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float reward;
+    bool done, success;
+    const bool ok = xh::lane_step_fast<float, FastLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
+    const int64_t e = late_index(e_in);
+    if (!ok) {
+        if (arm == 0) {
+            const int pos = atomicAdd(eject_count, 1);
+            eject_list[pos] = (int)e;
+        }
+        return;
+    }
+    ho_store(P, e, arm, L);
+    ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+    if (done && P.auto_reset && term_obs) ho_write_obs(L, e, arm, term_obs, ag_out, dg_out);
+    if (arm == 0) {
+        rew_out[e] = reward;
+        done_out[e] = done ? 1 : 0;
+        succ_out[e] = success ? 1 : 0;
+        if (done && P.auto_reset) {
+            const int pos = atomicAdd(done_count, 1);
+            done_list[pos] = (int)e;
+        }
+    }
+}
+
+// Row exchange of the cooperative Handover kernels (xarm_handover_coop_core.h): an environment owns two DPP rows of one
+// wavefront, rows 0 / 1 = arm 0 of env slots 0 / 1, rows 2 / 3 = arm 1, i.e. lane l and lane l + 32 are the same lane of the
+// two arms of one environment and ONE v_permlane32_swap_b32 (gfx950) hands a register across in both directions.
+struct SwapXchg {
+    int arm;
+    __device__ __forceinline__ void pair(float v, float &v0, float &v1) const {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v0 = __uint_as_float(r[0]);   // lanes 0-31 (arm 0) everywhere
+        v1 = __uint_as_float(r[1]);   // lanes 32-63 (arm 1) everywhere
+    }
+    __device__ __forceinline__ float from0(float v) const { float a, b; pair(v, a, b); return a; }
+    __device__ __forceinline__ float from1(float v) const { float a, b; pair(v, a, b); return b; }
+    __device__ __forceinline__ float partner(float v) const { float a, b; pair(v, a, b); return arm == 0 ? b : a; }
+    __device__ __forceinline__ void both(xc::LV<float> v, xc::LV<float> &v0, xc::LV<float> &v1) const { pair(v.v[0], v0.v[0], v1.v[0]); }
+};
+constexpr int HO_COOP_LDS_FLOATS = xk::LDS_T;     // only the joint motion axes S are staged by the cooperative core
+// XarmHandover.step of the envs list[0 .. *count) (null: all) on the cooperative rows: the hand-off of k_ho_step_fast.  The grid
+// is fixed (the count lives on the device); a workgroup walks the list with a grid stride, two envs per wavefront.  Lists
+// longer than P.eject_coop_cap belong to k_ho_step (launched beside this kernel; exactly one of the two does the work).
+template <typename Scene, bool FORCE_COUPLED>
+__global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                          float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                          uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                          int *__restrict__ done_list, int *__restrict__ done_count,
+                                                          const int *__restrict__ list, const int *__restrict__ count) {
+    __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (count && n > P.eject_coop_cap) return;
+    const int row = (int)(threadIdx.x >> 4), slot = row & 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    const SwapXchg x{row >> 1};
+    DevLds lds{smem + threadIdx.x};
+#pragma unroll 1
+    for (int64_t i0 = (int64_t)blockIdx.x * xhc::ROW_ENVS; i0 < n; i0 += (int64_t)gridDim.x * xhc::ROW_ENVS) {
+        const int64_t i_raw = i0 + slot;
+        const bool live = i_raw < n;
+        const int64_t i = live ? i_raw : n - 1;
+        const int64_t e_in = list ? (int64_t)list[i] : i;
+        xh::Lane<float> L;
+        ho_load(P, e_in, x.arm, L);
+        const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + x.arm];
+        const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+        float reward;
+        bool done, success;
+        xhc::env_step<float, DevLds, SwapXchg, Scene, FORCE_COUPLED>(G, x, L, act, reward, done, success, lds, P.hcfg.reward_type);
+        if (live && G.l == 0) {
+            const int64_t e = late_index(e_in);
+            ho_store(P, e, x.arm, L);
+            ho_write_obs(L, e, x.arm, obs_out, ag_out, dg_out);
+            if (done && P.auto_reset && term_obs) ho_write_obs(L, e, x.arm, term_obs, ag_out, dg_out);
+            if (x.arm == 0) {
+                rew_out[e] = reward;
+                done_out[e] = done ? 1 : 0;
+                succ_out[e] = success ? 1 : 0;
+                if (done && P.auto_reset) {
+                    const int pos = atomicAdd(done_count, 1);
+                    done_list[pos] = (int)e;
+                }
+            }
+        }
+    }
+}
+// XarmHandover.reset on the cooperative rows for the envs list[0 .. *count) (null: all), counts up to P.coop_limit (more:
+// k_ho_reset, launched beside this kernel): six ticks of latency for the handful of envs that finish in a step
+template <typename Scene>
+__global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                      float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+    __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n > P.coop_limit) return;
+    const int row = (int)(threadIdx.x >> 4), slot = row & 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    const SwapXchg x{row >> 1};
+    DevLds lds{smem + threadIdx.x};
+#pragma unroll 1
+    for (int64_t i0 = (int64_t)blockIdx.x * xhc::ROW_ENVS; i0 < n; i0 += (int64_t)gridDim.x * xhc::ROW_ENVS) {
+        const int64_t i_raw = i0 + slot;
+        const bool live = i_raw < n;
+        const int64_t i = live ? i_raw : n - 1;
+        const int64_t e_in = list ? (int64_t)list[i] : i;
+        xh::Lane<float> L;
+        ho_load(P, e_in, x.arm, L);
+        xhc::env_reset<float, DevLds, SwapXchg, Scene>(G, x, P.hcfg, e_in, L, lds);
+        if (live && G.l == 0) {
+            const int64_t e = late_index(e_in);
+            ho_store(P, e, x.arm, L);
+            if (obs_out) ho_write_obs(L, e, x.arm, obs_out, ag_out, dg_out);
+        }
+    }
 }
 
 // --------------------------------------------------------------------- XarmHandover-v0, num_obj = 2 (two lanes per env)
@@ -1035,6 +1182,7 @@ struct xarm_handle {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     int reset_overlap;
+    int ho_force_coupled; // test hook (XARM_HO_FORCE_COUPLED=1): every substep of the cooperative Handover step through the coupled sweep
     // StackTower: class-homogeneous wavefronts (xarm_stack_core.h class_layout); null when XARM_ST_CLASS_ORDER=0
     uint8_t *class_key;  // [E] row-set class of each env's last substep
     int *class_hist;     // [2 * NCLS] histogram, then the per-class arrival counters
@@ -1063,11 +1211,25 @@ static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
         if (_e != hipSuccess) return fail(h, XARM_E_HIP, #call ": %s", hipGetErrorString(_e)); \
     } while (0)
 
+// grid of a cooperative Handover launch over at most `cap` envs: two envs per wavefront, grid stride beyond 2 048 workgroups
+static unsigned ho_coop_grid(int64_t cap) {
+    const int64_t g = (cap + xhc::ROW_ENVS - 1) / xhc::ROW_ENVS;
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+// Handover reset of the envs in list[0 .. *count) (null: all): the cooperative rows take counts up to kp.coop_limit, the lane-pair
+// kernel the rest; both are launched, the one out of its range exits at once (the count lives on the device)
 static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
                             hipStream_t st) {
-    if (h->cfg.num_obj == 2) k_ho2_reset<<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
-    else if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
-    else k_ho_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    if (h->cfg.num_obj == 2) { k_ho2_reset<<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev); return; }
+    const int64_t cap = h->kp.num_envs < (int64_t)h->kp.coop_limit ? h->kp.num_envs : (int64_t)h->kp.coop_limit;
+    if (cap > 0) {
+        if (h->kp.hcfg.use_stand) k_ho_reset_coop<xh::HandoverStandScene><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        else k_ho_reset_coop<xh::HandoverScene><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    }
+    if (h->kp.num_envs > cap) {
+        if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        else k_ho_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+    }
 }
 
 static void launch_reach_reset(xarm_handle *h, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev, hipStream_t st) {
@@ -1184,15 +1346,24 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
             h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
     }
     const bool handover2 = handover && cfg->num_obj == 2;
-    // fast-step pipeline (PickAndPlace batches above the cooperative limit): on unless the caller pinned the
-    // one-env-per-lane family (step_coop_limit < 0: bitwise world-size invariance, gym_xarm_amd.distributed) or
-    // XARM_STEP_PIPELINE=0 asks for the plain k_step
-    h->fast_pipeline = (cfg->env_kind == XARM_ENV_PICK_AND_PLACE && cfg->step_coop_limit >= 0 && cfg->auto_reset != XARM_AUTO_RESET_LAZY) ? 1 : 0;
+    const bool handover1 = handover && !handover2;
+    // cooperative reset of Handover (one stick): two rows per env, measured cross-over against the lane-pair reset
+    if (handover1) {
+        h->kp.coop_limit = cfg->reset_coop_limit > 0 ? cfg->reset_coop_limit : (cfg->reset_coop_limit < 0 ? 0 : XARM_HO_RESET_COOP_LIMIT_DEFAULT);
+        const char *ev = getenv("XARM_RESET_COOP_LIMIT");
+        if (ev && *ev && cfg->reset_coop_limit == 0) h->kp.coop_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+    }
+    // fast-step pipeline (PickAndPlace batches above the cooperative limit, Handover with one stick): on unless the caller
+    // pinned the one-env-per-lane family (step_coop_limit < 0: gym_xarm_amd.distributed.reproducible_limits('lane')) or
+    // XARM_STEP_PIPELINE=0 asks for the plain k_step / k_ho_step
+    h->fast_pipeline = ((cfg->env_kind == XARM_ENV_PICK_AND_PLACE || handover1) && cfg->step_coop_limit >= 0 && cfg->auto_reset != XARM_AUTO_RESET_LAZY) ? 1 : 0;
     {
         const char *ev = getenv("XARM_STEP_PIPELINE");
         if (ev && *ev) h->fast_pipeline = h->fast_pipeline && atoi(ev) != 0;
+        ev = getenv("XARM_HO_FORCE_COUPLED");
+        h->ho_force_coupled = ev && *ev && atoi(ev) != 0;
     }
-    h->kp.eject_coop_cap = XARM_EJECT_COOP_CAP;
+    h->kp.eject_coop_cap = handover1 ? XARM_HO_EJECT_COOP_CAP : XARM_EJECT_COOP_CAP;
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover2 ? xh2::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM)));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
@@ -1345,12 +1516,42 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else if (handover && h->cfg.num_obj == 2)
         k_ho2_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                         terminal_obs_dev, h->done_list, cnt);
+    else if (handover && h->fast_pipeline) {
+        // as for PickAndPlace below: every env on the pad-free fast lane-pair step, the ones with an active finger-pad row
+        // handed off, untouched, to the cooperative rows (lists of at most eject_coop_cap envs) or to k_ho_step (longer)
+        pipelined = true;
+        const bool stand = h->kp.hcfg.use_stand != 0;
+        if (stand) k_ho_step_fast<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                             terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
+        else k_ho_step_fast<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                  terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
+        if (overlap) {
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->side);
+            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+        }
+        const int64_t cap = h->kp.num_envs < (int64_t)h->kp.eject_coop_cap ? h->kp.num_envs : (int64_t)h->kp.eject_coop_cap;
+        int *list_b = overlap ? h->done_list_b : h->done_list, *cnt_b = overlap ? h->eject_count + 1 : cnt;
+        if (stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+        else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+        else k_ho_step_coop_list<xh::HandoverScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+        if (h->kp.num_envs > cap) {
+            if (stand) k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                            terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+            else k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                 terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+        }
+    }
     else if (handover && h->kp.hcfg.use_stand)
         k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                           success_dev, terminal_obs_dev, h->done_list, cnt);
+                                                                           success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     else if (handover)
         k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                      success_dev, terminal_obs_dev, h->done_list, cnt);
+                                                                      success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     else if (reach && h->kp.num_envs <= (int64_t)h->coop_step_limit)
         k_reach_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
             h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt);
@@ -1392,7 +1593,8 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                 terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
     if (h->kp.auto_reset && pipelined && overlap) {
-        launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
+        if (handover) launch_ho_reset(h, 2 * grid, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
+        else launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     } else if (h->kp.auto_reset) {
         if (reach) launch_reach_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);

@@ -81,7 +81,7 @@ typedef struct xarm_config {
                                VecEnv semantics); XARM_AUTO_RESET_LAZY: see below */
     int32_t device;         /* HIP device ordinal */
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
-    int32_t reset_coop_limit; /* PickAndPlace, Reach: resets of at most this many envs per call run on the cooperative
+    int32_t reset_coop_limit; /* PickAndPlace, Reach, Handover (one stick): resets of at most this many envs per call run on the cooperative
                                (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
     int32_t step_coop_limit;  /* PickAndPlace, Reach: a handle of at most this many envs also STEPS on the cooperative kernel
                                  (the one-env-per-lane launch would leave most SIMDs without a wavefront);
@@ -104,6 +104,14 @@ typedef struct xarm_config {
  * stream-ordered call.  XARM_RESET_OVERLAP=0 in the environment at xarm_create keeps everything on the caller's stream. */
 /* PickAndPlace handles of at most this many envs step on the cooperative kernel as well (env XARM_STEP_COOP_LIMIT) */
 #define XARM_STEP_COOP_LIMIT_DEFAULT 8192
+/* XarmHandover with one stick steps the same way at every batch size (unless step_coop_limit < 0 or XARM_STEP_PIPELINE=0 select
+ * the plain lane-pair k_ho_step): the pad-free fast lane-pair kernel, then the envs with an active finger-pad row on either arm
+ * (~4 %) on the cooperative rows - TWO 16-lane rows per env, one per arm (csrc/xarm_handover_coop_core.h).  Hand-offs of more
+ * than XARM_HO_EJECT_COOP_CAP envs go to k_ho_step instead (2 048 cooperative wavefronts per round of ~0.5 ms against 2.3 ms);
+ * resets of at most XARM_HO_RESET_COOP_LIMIT_DEFAULT envs (reset_coop_limit / XARM_RESET_COOP_LIMIT override) run on the
+ * cooperative rows too. */
+#define XARM_HO_EJECT_COOP_CAP 8192
+#define XARM_HO_RESET_COOP_LIMIT_DEFAULT 4096
 
 typedef struct xarm_dims_t {
     int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;

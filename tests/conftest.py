@@ -48,7 +48,7 @@ class HostCore:
         so = os.path.join(d, "libxarm_host.so")
         srcs = [os.path.join(d, "xarm_host.cpp")] + [os.path.join(ROOT, "gym_xarm_amd", "csrc", f) for f in (
             "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h", "xarm_stack_core.h",
-            "xarm_coop_core.h", "xarm_reach_coop_core.h")]
+            "xarm_coop_core.h", "xarm_reach_coop_core.h", "xarm_handover_coop_core.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
                                    "-o", so, srcs[0]])
@@ -222,6 +222,31 @@ class HostCore:
         mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
         self.L.xh_ho_reset(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st), mk,
                            self._p(obs), self._p(ag), self._p(dg))
+        return st, obs, ag, dg
+
+    def hoc_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1, rt=0, use_stand=0, mode="coop"):
+        """XarmHandover.step on the cooperative rows (csrc/xarm_handover_coop_core.h; mode 'coop', 'coupled' = every substep
+        forced through the coupled sweep) or on the pad-free fast lane pair (mode 'fast'); returns ok[e] last: False = a pad
+        row was active during the fast step and row e came back untouched"""
+        E = state.shape[0]
+        self.L.xh_ho_set_reward_type(C.c_int(rt))
+        self.L.xh_ho_set_use_stand(C.c_int(use_stand))
+        st = np.array(state, dtype=np.float64, copy=True)
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        obs, ag, dg = np.zeros((E, 29)), np.zeros((E, 3)), np.zeros((E, 3))
+        rew, done, succ, ok = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.ones(E, np.uint8)
+        self.L.xh_hoc_step(C.c_int(f32), C.c_int({"coop": 0, "coupled": 2, "fast": 4}[mode]), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs),
+                           C.c_int64(E), self._p(st), self._p(a), self._p(obs), self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ), self._u8(ok))
+        return st, obs, ag, dg, rew, done, succ, ok.astype(bool)
+
+    def hoc_reset(self, state, mask=None, f32=1, seed=0, off=0, ssr=0.5, gs=1, use_stand=0, forced=False):
+        E = state.shape[0]
+        self.L.xh_ho_set_use_stand(C.c_int(use_stand))
+        st = np.array(state, dtype=np.float64, copy=True)
+        obs, ag, dg = np.zeros((E, 29)), np.zeros((E, 3)), np.zeros((E, 3))
+        mk = None if mask is None else self._u8(np.ascontiguousarray(mask, dtype=np.uint8))
+        self.L.xh_hoc_reset(C.c_int(f32), C.c_int(1 if forced else 0), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st), mk,
+                            self._p(obs), self._p(ag), self._p(dg))
         return st, obs, ag, dg
 
     # ---- Handover with num_obj = 2 (csrc/xarm_handover2_core.h)

@@ -13,6 +13,7 @@
 #include "../../gym_xarm_amd/csrc/xarm_handover2_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_stack_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_coop_core.h"
+#include "../../gym_xarm_amd/csrc/xarm_handover_coop_core.h"
 #include "../../gym_xarm_amd/csrc/xarm_reach_coop_core.h"
 #include <pthread.h>
 #include <string.h>
@@ -314,6 +315,83 @@ template <typename T> void ho_run(int mode, const xh::EnvCfg &cfg, int64_t E, do
 }
 }
 
+
+// ---- Handover, pad-free fast lane-pair step (xh::lane_step_fast) and the cooperative rows (xarm_handover_coop_core.h):
+// the two rows of an environment run as two host threads (each carries its 16 lane values in LV<T>), the row exchange
+// (v_permlane32_swap on the device) is a 16-wide slot + barrier
+namespace {
+struct RowShared { SpinBarrier bar; double slot[2][xc::GL]; };
+struct RowXchg {
+    RowShared *sh; int arm;
+    template <typename T> void pair(T v, T &v0, T &v1) const {
+        sh->slot[arm][0] = (double)v;
+        sh->bar.wait();
+        v0 = (T)sh->slot[0][0]; v1 = (T)sh->slot[1][0];
+        sh->bar.wait();
+    }
+    template <typename T> T from0(T v) const { T a, b; pair(v, a, b); return a; }
+    template <typename T> T from1(T v) const { T a, b; pair(v, a, b); return b; }
+    template <typename T> T partner(T v) const { T a, b; pair(v, a, b); return arm == 0 ? b : a; }
+    template <typename T> void both(xc::LV<T> v, xc::LV<T> &v0, xc::LV<T> &v1) const {
+        for (int i = 0; i < xc::GL; i++) sh->slot[arm][i] = (double)v.v[i];
+        sh->bar.wait();
+        for (int i = 0; i < xc::GL; i++) { v0.v[i] = (T)sh->slot[0][i]; v1.v[i] = (T)sh->slot[1][i]; }
+        sh->bar.wait();
+    }
+};
+template <typename T> struct HocJob {
+    int mode;   // 0 step, 1 reset, 2 step forced through the coupled sweep, 3 reset forced coupled, 4 the fast lane-pair step
+    xh::EnvCfg cfg; int64_t E; double *state; const double *act; const uint8_t *mask;
+    double *obs, *ag, *dg, *rew; uint8_t *done, *succ, *ok; PairShared *psh; RowShared *rsh; int arm;
+};
+template <typename T, typename Scene> void hoc_env(HocJob<T> &J, int64_t e) {
+    RowXchg x{J.rsh, J.arm};
+    PairXchg px{J.psh, J.arm};
+    const xc::Grp G{};
+    xh::Lane<T> L; T lds[xk::LDS_FLOATS]; HostLds<T> hl{lds};
+    hload(J.state + e * xh::STATE_DIM, J.arm, L);
+    T r = 0; bool d = false, su = false, ok = true;
+    T a[4] = {0, 0, 0, 0};
+    if (J.act) for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
+    if (J.mode == 0) xhc::env_step<T, HostLds<T>, RowXchg, Scene, false>(G, x, L, a, r, d, su, hl, J.cfg.reward_type);
+    else if (J.mode == 2) xhc::env_step<T, HostLds<T>, RowXchg, Scene, true>(G, x, L, a, r, d, su, hl, J.cfg.reward_type);
+    else if (J.mode == 1) xhc::env_reset<T, HostLds<T>, RowXchg, Scene, false>(G, x, J.cfg, e, L, hl);
+    else if (J.mode == 3) xhc::env_reset<T, HostLds<T>, RowXchg, Scene, true>(G, x, J.cfg, e, L, hl);
+    else ok = xh::lane_step_fast<T, HostLds<T>, PairXchg, Scene>(L, J.arm, a, r, d, su, hl, px, J.cfg.reward_type);
+    T o8[8];
+    xh::arm_obs(L, J.arm, o8);
+    J.rsh->bar.wait();   // both rows finished computing before anyone overwrites the state row
+    if (ok) {
+        hstore(L, J.arm, J.state + e * xh::STATE_DIM);
+        double *o = J.obs + e * xh::OBS_DIM;
+        for (int k = 0; k < 8; k++) o[13 + 8 * J.arm + k] = o8[k];
+        if (J.arm == 0) {
+            for (int k = 0; k < 3; k++) { o[k] = L.st.bp[k]; o[7 + k] = L.st.bv[k]; o[10 + k] = L.st.bw[k]; J.ag[e * 3 + k] = L.st.bp[k]; J.dg[e * 3 + k] = L.st.goal[k]; }
+            for (int k = 0; k < 4; k++) o[3 + k] = L.st.bq[k];
+            if (J.rew) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
+        }
+    }
+    if (J.arm == 0 && J.ok) J.ok[e] = ok;
+    J.rsh->bar.wait();
+}
+template <typename T> void *hoc_thread(void *p) {
+    HocJob<T> &J = *(HocJob<T> *)p;
+    for (int64_t e = 0; e < J.E; e++) {
+        if ((J.mode == 1 || J.mode == 3) && J.mask && !J.mask[e]) continue;
+        if (J.cfg.use_stand) hoc_env<T, xh::HandoverStandScene>(J, e); else hoc_env<T, xh::HandoverScene>(J, e);
+    }
+    return 0;
+}
+template <typename T> void hoc_run(int mode, const xh::EnvCfg &cfg, int64_t E, double *state, const double *act, const uint8_t *mask,
+                                   double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, uint8_t *ok) {
+    PairShared psh; RowShared rsh;
+    HocJob<T> j[2];
+    pthread_t th[2];
+    for (int a = 0; a < 2; a++) { j[a] = HocJob<T>{mode, cfg, E, state, act, mask, obs, ag, dg, rew, done, succ, ok, &psh, &rsh, a}; pthread_create(&th[a], 0, hoc_thread<T>, &j[a]); }
+    for (int a = 0; a < 2; a++) pthread_join(th[a], 0);
+}
+}
+
 extern "C" {
 static int g_ho_reward_type = 0, g_ho_use_stand = 0;
 void xh_ho_set_reward_type(int rt) { g_ho_reward_type = rt; }   // 0 sparse, 1 the staged dense reward
@@ -333,6 +411,15 @@ void xh_ho_step(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t
 void xh_ho_reset(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
     auto c = hcfg(seed, off, ssr, gs);
     if (f32) ho_run<float>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0); else ho_run<double>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0);
+}
+// mode: 0 cooperative rows, 2 cooperative rows forced through the coupled sweep, 4 the pad-free fast lane-pair step (ok[e] = 0: a pad row was active, row e untouched)
+void xh_hoc_step(int f32, int mode, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, uint8_t *ok) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) hoc_run<float>(mode, c, E, state, act, 0, obs, ag, dg, rew, done, succ, ok); else hoc_run<double>(mode, c, E, state, act, 0, obs, ag, dg, rew, done, succ, ok);
+}
+void xh_hoc_reset(int f32, int forced, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const uint8_t *mask, double *obs, double *ag, double *dg) {
+    auto c = hcfg(seed, off, ssr, gs);
+    if (f32) hoc_run<float>(forced ? 3 : 1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0, 0); else hoc_run<double>(forced ? 3 : 1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0, 0);
 }
 static xr::EnvCfg rcfg(uint64_t seed, int64_t off, int rt) { xr::EnvCfg c; c.seed = seed; c.env_id_offset = off; c.reward_type = rt; return c; }
 void xh_reach_init(int f32, uint64_t seed, int64_t off, int rt, int64_t E, double *state) { auto c = rcfg(seed, off, rt); if (f32) reach_init<float>(c, E, state); else reach_init<double>(c, E, state); }

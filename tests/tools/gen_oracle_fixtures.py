@@ -160,6 +160,28 @@ def _ezpolicy(o):
     return a
 
 
+class JitteredHandover:
+    """The reference's ezpolicy (xarm_handover.py:404-446, restated above) as a closed-loop policy on OBSERVATIONS with
+    per-env jitter: a start delay, a constant steering bias and per-step action noise, so that a batch covers the
+    reach, the first grasp, the lift, the second arm's approach and the two-arm phase at many different phases at once
+    (tests/test_handover_coop.py: live-oracle step parity of both Handover kernel families)."""
+
+    def __init__(self, E, seed=0, horizon=36):
+        rng = np.random.default_rng(seed)
+        self.delay = rng.integers(0, 6, E)
+        self.bias = rng.uniform(-0.15, 0.15, (E, 8))
+        self.bias[:, [3, 7]] = 0.0
+        self.rng = rng
+        self.horizon = horizon
+
+    def __call__(self, obs, t):
+        E = obs.shape[0]
+        a = np.array([_ezpolicy(obs[e]) for e in range(E)], dtype=np.float64)
+        a += self.bias + self.rng.uniform(-0.1, 0.1, (E, 8)) * np.array([1, 1, 1, 0, 1, 1, 1, 0])
+        a[t < self.delay] = 0.0
+        return np.clip(a, -1, 1)
+
+
 def handover():
     """XarmHandover-v0: 24 envs under the reference's scripted handover policy for 30 steps + 8 random steps, with
     sensitivities of the continuous state (q, qd of both arms, object pose / velocity)."""

@@ -7,8 +7,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libxarm_hip.so")
-SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h",
+# one translation unit per kernel family (the fused kernels take ~30 s each to compile; the units are compiled in parallel)
+UNITS = ["xarm_hip.hip", "xarm_k_pnp.hip", "xarm_k_pnp_coop.hip", "xarm_k_reach.hip", "xarm_k_handover.hip", "xarm_k_handover_coop.hip",
+         "xarm_k_handover2.hip", "xarm_k_stack.hip"]
+HEADERS = ["xarm_dev.h", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h",
            "xarm_stack_core.h", "xarm_coop_core.h", "xarm_reach_coop_core.h", "xarm_handover_coop_core.h"]
+SOURCES = UNITS + HEADERS
 # -fno-slp-vectorize: LLVM's SLP pass pairs the scalar fp32 ops of the unrolled solver into v_pk_* instructions,
 # which need even-aligned register pairs; in this 400-live-value kernel that costs ~30 % extra v_mov and pushes
 # 1.3 KB/lane into scratch.  Without it the step kernel needs 28 B/lane of scratch and 18 % fewer instructions.
@@ -19,7 +23,7 @@ SOURCES = ["xarm_hip.hip", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h
 # sweep (168 B/lane, outside the Gauss-Seidel loop; +19 MB of L2<->fabric traffic per 65 536-env launch).
 # XARM_SCHED=default builds with LLVM's default scheduler instead (0 B scratch, ~13 % slower).
 _SCHED = [] if os.environ.get("XARM_SCHED", "ilp") == "default" else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"] + _SCHED
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize"] + _SCHED
 
 def find_hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -36,18 +40,33 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    """Regenerate the model header and compile csrc/xarm_hip.hip -> csrc/libxarm_hip.so."""
-    gen = os.path.join(os.path.dirname(HERE), "tools", "gen_model_header.py")
-    if os.path.exists(gen):
-        subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
-    if not force and not stale():
-        return LIB
-    cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB, os.path.join(CSRC, "xarm_hip.hip")]
+def _compile(args):
+    cmd, verbose = args
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+
+
+def build(force=False, verbose=True, extra_flags=(), lib=LIB, jobs=None):
+    """Regenerate the model header, compile csrc/xarm_*.hip (in parallel) and link csrc/libxarm_hip.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    gen = os.path.join(os.path.dirname(HERE), "tools", "gen_model_header.py")
+    if os.path.exists(gen):
+        subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
+    if not force and lib == LIB and not stale():
+        return lib
+    hipcc = find_hipcc()
+    objdir = os.path.join(CSRC, "build" if lib == LIB else "build_" + os.path.splitext(os.path.basename(lib))[0])
+    os.makedirs(objdir, exist_ok=True)
+    objs, jobs_l = [], []
+    for u in UNITS:
+        o = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
+        objs.append(o)
+        jobs_l.append(([hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, u)], verbose))
+    with ThreadPoolExecutor(jobs or min(len(UNITS), os.cpu_count() or 1)) as ex:
+        list(ex.map(_compile, jobs_l))
+    _compile(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, verbose))
+    return lib
 
 
 def build_example(verbose=True):

@@ -1,0 +1,184 @@
+// xarm_k_handover_coop.hip - XarmHandover-v0 (one stick): the pad-free fast lane-pair step and the cooperative rows (two 16-lane rows per environment).
+// Part of libxarm_hip.so (gfx950); shared declarations: xarm_dev.h, C ABI: xarm_hip.hip.
+#include "xarm_dev.h"
+
+namespace xd {
+
+// The fast Handover step: XarmHandover.step on the pad-free lane-pair substep for every env (xh::lane_step_fast).  An env none
+// of whose finger pads comes within the solver margin of the stick during the step is finished here; an env with an active
+// pad row on either arm stores NOTHING and is appended to eject_list: it is stepped again, from its untouched state, by
+// k_ho_step_coop_list (or k_ho_step when the list is long).  Why: a wavefront of k_ho_step with ONE such lane sweeps the pad
+// blocks for all 32 of its envs (2.3 ms against 0.96 ms for a contact-free batch, tools/ho_time.py).  Only the support-slot
+// columns live in LDS.
+template <typename Scene>
+__global__ __launch_bounds__(WG) void k_ho_step_fast(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                     float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                     float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                     uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                     int *__restrict__ done_list, int *__restrict__ done_count,
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count) {
+    __shared__ float smem[FAST_LDS_FLOATS * WG];
+    const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
+    const int arm = (int)(t & 1);
+    if (e_in >= P.num_envs) return;
+    FastLds lds{smem + threadIdx.x};
+    xh::Lane<float> L;
+    ho_load(P, e_in, arm, L);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float reward;
+    bool done, success;
+    const bool ok = xh::lane_step_fast<float, FastLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
+    const int64_t e = late_index(e_in);
+    if (!ok) {
+        if (arm == 0) {
+            const int pos = atomicAdd(eject_count, 1);
+            eject_list[pos] = (int)e;
+        }
+        return;
+    }
+    ho_store(P, e, arm, L);
+    ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
+    if (done && P.auto_reset && term_obs) ho_write_obs(L, e, arm, term_obs, ag_out, dg_out);
+    if (arm == 0) {
+        rew_out[e] = reward;
+        done_out[e] = done ? 1 : 0;
+        succ_out[e] = success ? 1 : 0;
+        if (done && P.auto_reset) {
+            const int pos = atomicAdd(done_count, 1);
+            done_list[pos] = (int)e;
+        }
+    }
+}
+
+template __global__ void k_ho_step_fast<xh::HandoverScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                     float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                     float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                     uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                     int *__restrict__ done_list, int *__restrict__ done_count,
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count);
+template __global__ void k_ho_step_fast<xh::HandoverStandScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                     float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                     float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                     uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                     int *__restrict__ done_list, int *__restrict__ done_count,
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count);
+
+// Row exchange of the cooperative Handover kernels (xarm_handover_coop_core.h): an environment owns two DPP rows of one
+// wavefront, rows 0 / 1 = arm 0 of env slots 0 / 1, rows 2 / 3 = arm 1, i.e. lane l and lane l + 32 are the same lane of the
+// two arms of one environment and ONE v_permlane32_swap_b32 (gfx950) hands a register across in both directions.
+struct SwapXchg {
+    int arm;
+    __device__ __forceinline__ void pair(float v, float &v0, float &v1) const {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v0 = __uint_as_float(r[0]);   // lanes 0-31 (arm 0) everywhere
+        v1 = __uint_as_float(r[1]);   // lanes 32-63 (arm 1) everywhere
+    }
+    __device__ __forceinline__ float from0(float v) const { float a, b; pair(v, a, b); return a; }
+    __device__ __forceinline__ float from1(float v) const { float a, b; pair(v, a, b); return b; }
+    __device__ __forceinline__ float partner(float v) const { float a, b; pair(v, a, b); return arm == 0 ? b : a; }
+    __device__ __forceinline__ void both(xc::LV<float> v, xc::LV<float> &v0, xc::LV<float> &v1) const { pair(v.v[0], v0.v[0], v1.v[0]); }
+};
+
+// XarmHandover.step of the envs list[0 .. *count) (null: all) on the cooperative rows: the hand-off of k_ho_step_fast.  The grid
+// is fixed (the count lives on the device); a workgroup walks the list with a grid stride, two envs per wavefront.  Lists
+// longer than P.eject_coop_cap belong to k_ho_step (launched beside this kernel; exactly one of the two does the work).
+template <typename Scene, bool FORCE_COUPLED>
+__global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                          float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                          uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                          int *__restrict__ done_list, int *__restrict__ done_count,
+                                                          const int *__restrict__ list, const int *__restrict__ count) {
+    __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (count && n > P.eject_coop_cap) return;
+    const int row = (int)(threadIdx.x >> 4), slot = row & 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    const SwapXchg x{row >> 1};
+    DevLds lds{smem + threadIdx.x};
+#pragma unroll 1
+    for (int64_t i0 = (int64_t)blockIdx.x * xhc::ROW_ENVS; i0 < n; i0 += (int64_t)gridDim.x * xhc::ROW_ENVS) {
+        const int64_t i_raw = i0 + slot;
+        const bool live = i_raw < n;
+        const int64_t i = live ? i_raw : n - 1;
+        const int64_t e_in = list ? (int64_t)list[i] : i;
+        xh::Lane<float> L;
+        ho_load(P, e_in, x.arm, L);
+        const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + x.arm];
+        const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+        float reward;
+        bool done, success;
+        xhc::env_step<float, DevLds, SwapXchg, Scene, FORCE_COUPLED>(G, x, L, act, reward, done, success, lds, P.hcfg.reward_type);
+        if (live && G.l == 0) {
+            const int64_t e = late_index(e_in);
+            ho_store(P, e, x.arm, L);
+            ho_write_obs(L, e, x.arm, obs_out, ag_out, dg_out);
+            if (done && P.auto_reset && term_obs) ho_write_obs(L, e, x.arm, term_obs, ag_out, dg_out);
+            if (x.arm == 0) {
+                rew_out[e] = reward;
+                done_out[e] = done ? 1 : 0;
+                succ_out[e] = success ? 1 : 0;
+                if (done && P.auto_reset) {
+                    const int pos = atomicAdd(done_count, 1);
+                    done_list[pos] = (int)e;
+                }
+            }
+        }
+    }
+}
+
+template __global__ void k_ho_step_coop_list<xh::HandoverScene, false>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                          float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                          uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                          int *__restrict__ done_list, int *__restrict__ done_count,
+                                                          const int *__restrict__ list, const int *__restrict__ count);
+template __global__ void k_ho_step_coop_list<xh::HandoverScene, true>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                          float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                          uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                          int *__restrict__ done_list, int *__restrict__ done_count,
+                                                          const int *__restrict__ list, const int *__restrict__ count);
+template __global__ void k_ho_step_coop_list<xh::HandoverStandScene, false>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                          float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                          uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                          int *__restrict__ done_list, int *__restrict__ done_count,
+                                                          const int *__restrict__ list, const int *__restrict__ count);
+
+// XarmHandover.reset on the cooperative rows for the envs list[0 .. *count) (null: all), counts up to P.coop_limit (more:
+// k_ho_reset, launched beside this kernel): six ticks of latency for the handful of envs that finish in a step
+template <typename Scene>
+__global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                      float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
+    __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
+    const int64_t n = count ? (int64_t)*count : P.num_envs;
+    if (n > P.coop_limit) return;
+    const int row = (int)(threadIdx.x >> 4), slot = row & 1;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    const SwapXchg x{row >> 1};
+    DevLds lds{smem + threadIdx.x};
+#pragma unroll 1
+    for (int64_t i0 = (int64_t)blockIdx.x * xhc::ROW_ENVS; i0 < n; i0 += (int64_t)gridDim.x * xhc::ROW_ENVS) {
+        const int64_t i_raw = i0 + slot;
+        const bool live = i_raw < n;
+        const int64_t i = live ? i_raw : n - 1;
+        const int64_t e_in = list ? (int64_t)list[i] : i;
+        xh::Lane<float> L;
+        ho_load(P, e_in, x.arm, L);
+        xhc::env_reset<float, DevLds, SwapXchg, Scene>(G, x, P.hcfg, e_in, L, lds);
+        if (live && G.l == 0) {
+            const int64_t e = late_index(e_in);
+            ho_store(P, e, x.arm, L);
+            if (obs_out) ho_write_obs(L, e, x.arm, obs_out, ag_out, dg_out);
+        }
+    }
+}
+
+template __global__ void k_ho_reset_coop<xh::HandoverScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                      float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
+template __global__ void k_ho_reset_coop<xh::HandoverStandScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                      float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
+
+} // namespace xd

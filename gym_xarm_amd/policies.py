@@ -106,16 +106,16 @@ class HandoverEzPolicy:
         obj, g1, q1, g2, q2 = o[:, 0:3], o[:, 13:16], o[:, 19], o[:, 21:24], o[:, 27]
         n1, n2 = (obj - g1).norm(dim=1), (obj - g2).norm(dim=1)
         ig1, ig2 = (q1 < 0.25) & (n1 < 0.05), (q2 < 0.25) & (n2 < 0.05)
-        d1 = obj - g1 + torch.tensor([-0.07, 0.0, 0.0], device=o.device)
-        d2 = obj - g2 + torch.tensor([0.07, 0.0, 0.0], device=o.device)
-        a = torch.zeros(o.shape[0], 8, device=o.device)
+        d1 = obj - g1 + torch.tensor([-0.07, 0.0, 0.0], device=o.device, dtype=o.dtype)
+        d2 = obj - g2 + torch.tensor([0.07, 0.0, 0.0], device=o.device, dtype=o.dtype)
+        a = torch.zeros(o.shape[0], 8, device=o.device, dtype=o.dtype)
         a[:, 3] = torch.where(n1 < 0.1, -0.5, 0.5)
         a[:, 7] = torch.where(n2 < 0.1, -0.5, 0.5)
         reach1 = ~ig1
         lift1 = ig1 & ~ig2
         both = ig1 & ig2
         a[:, 0:3] = torch.where(reach1[:, None], d1 / d1.norm(dim=1, keepdim=True), a[:, 0:3])
-        a[:, 0:3] = torch.where(lift1[:, None], torch.tensor([0.5, 0.0, 0.5], device=o.device).expand_as(d1), a[:, 0:3])
+        a[:, 0:3] = torch.where(lift1[:, None], torch.tensor([0.5, 0.0, 0.5], device=o.device, dtype=o.dtype).expand_as(d1), a[:, 0:3])
         a[:, 4:7] = torch.where(lift1[:, None], d2 / d2.norm(dim=1, keepdim=True), a[:, 4:7])
         a[:, 4] = torch.where(both, torch.full_like(a[:, 4], -0.5), a[:, 4])
         return a

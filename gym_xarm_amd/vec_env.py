@@ -371,7 +371,8 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
                                   _native.REWARD_TYPES[self.config["reward_type"]],
                                   1 if self.config["goal_shape"] == "ground" else 0, 0.0, 0.0, int(self._auto_reset),
                                   self.device.index if self.device.index is not None else torch.cuda.current_device(),
-                                  float(self.config["same_side_rate"]), 0, 0, int(bool(self.config["use_stand"])))
+                                  float(self.config["same_side_rate"]), int(self._reset_coop_limit), int(self._step_coop_limit),
+                                  int(bool(self.config["use_stand"])))
 
     def debug_substeps(self, q_target, n):
         raise NotImplementedError

@@ -356,3 +356,24 @@ def test_gpu_handover_use_stand(oracle):
     assert n_tight >= 0.8 * n
     # without the flag the same scene lets the sticks fall (and the default config rejects nothing)
     env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ezpolicy_against_the_reference_vectors(gref):
+    """HandoverEzPolicy on device tensors == the reference's own XarmHandover.ezpolicy (tests/golden, tools/gen_golden.py) on
+    every row away from the 0.05 / 0.1 shells, and it drives the HIP env (observation layout = the reference's, :406-418)"""
+    import torch
+    import gym_xarm_amd as gx
+    from gym_xarm_amd.policies import HandoverEzPolicy
+    obs, act = gref["ez_observation"], gref["ez_action"]
+    n1, n2 = np.linalg.norm(obs[:, 0:3] - obs[:, 13:16], axis=1), np.linalg.norm(obs[:, 0:3] - obs[:, 21:24], axis=1)
+    clear = (np.abs(n1 - 0.05) > 1e-5) & (np.abs(n1 - 0.1) > 1e-5) & (np.abs(n2 - 0.05) > 1e-5) & (np.abs(n2 - 0.1) > 1e-5)
+    out = HandoverEzPolicy()({"observation": torch.tensor(obs, dtype=torch.float32, device="cuda")}).cpu().numpy()
+    np.testing.assert_allclose(out[clear], act[clear], atol=2e-5)
+    env = gx.make("XarmPDHandover-v0", num_envs=64, seed=5, auto_reset=False)
+    o = env.reset()
+    a = HandoverEzPolicy()(o)
+    assert a.shape == (64, 8) and a.device.type == "cuda" and torch.isfinite(a).all()
+    d1 = o["observation"][:, 0:3] - o["observation"][:, 13:16] + torch.tensor([-0.07, 0.0, 0.0], device="cuda")
+    assert torch.allclose(a[:, 0:3], d1 / d1.norm(dim=1, keepdim=True), atol=1e-6)      # every env starts in the reach branch
+    env.close()

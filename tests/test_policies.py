@@ -40,3 +40,29 @@ def test_handover_ezpolicy_stage_table_on_the_oracle(oracle, oracle_torch_env):
     env = oracle_torch_env(oracle.OracleHandover(64, seed=11))
     rel = handover_stages(env, 60, HandoverReleasePolicy(env))
     assert rel["handed"] > 2 * st["handed"] + 0.1 and rel["held_end"] > 0.15, (st, rel)        # 0.42 / 0.27 with the release step
+
+
+def test_ezpolicy_matches_the_reference_code():
+    """HandoverEzPolicy (the tensor form) and the fixture generator's restatement against the actions the reference's OWN
+    XarmHandover.ezpolicy (xarm_handover.py:404-446) returns on 640 observation rows covering every branch - reach, lift,
+    both-hold, the 0.05 / 0.1 shells, finger openings either side of the 0.25 test (tools/gen_golden.py)"""
+    import os
+    import sys
+    import torch
+    from gym_xarm_amd.policies import HandoverEzPolicy
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "handover_reward_reference.npz"))
+    obs, act = g["ez_observation"], g["ez_action"]
+    out = HandoverEzPolicy()({"observation": torch.tensor(obs, dtype=torch.float64)}).numpy()
+    np.testing.assert_allclose(out, act, atol=1e-12)
+    # float32 observations (what the device env returns): identical away from the shells, where a rounded norm may fall on the other side
+    n1, n2 = np.linalg.norm(obs[:, 0:3] - obs[:, 13:16], axis=1), np.linalg.norm(obs[:, 0:3] - obs[:, 21:24], axis=1)
+    clear = (np.abs(n1 - 0.05) > 1e-5) & (np.abs(n1 - 0.1) > 1e-5) & (np.abs(n2 - 0.05) > 1e-5) & (np.abs(n2 - 0.1) > 1e-5)
+    out32 = HandoverEzPolicy()({"observation": torch.tensor(obs, dtype=torch.float32)}).numpy()
+    assert clear.mean() > 0.95
+    np.testing.assert_allclose(out32[clear], act[clear], atol=2e-5)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from gen_oracle_fixtures import _ezpolicy
+    mine = np.array([np.asarray(_ezpolicy(obs[i]), dtype=np.float64) for i in range(obs.shape[0])])
+    np.testing.assert_allclose(mine, act, atol=1e-12)
+    branches = {(bool(a[3] < 0), bool(a[7] < 0), bool(np.abs(a[0:3]).sum() > 0), bool(np.abs(a[4:7]).sum() > 0)) for a in act}
+    assert len(branches) >= 6

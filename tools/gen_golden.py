@@ -230,6 +230,29 @@ def handover():
     except ValueError:
         out["n2_dense_raises"] = np.uint8(1)
     assert out["n2_dense_raises"] == 1
+    # the scripted controller XarmHandover.ezpolicy (:404-446): pure NumPy on the observation dict.  Rows cover every branch:
+    # reach (arm 1 far / inside the 0.1 closing shell / inside the 0.05 grasp shell), lift (arm 1 holds, arm 2 far / near),
+    # both hold, the thresholds themselves (0.05 and 0.1 +- 2e-3) and finger openings on both sides of the 0.25 test
+    rng3 = np.random.default_rng(779)
+    ne = 640
+    eo = np.zeros((ne, 29))
+    eo[:, 0:3] = rng3.uniform([-0.28, -0.18, 0.02], [0.28, 0.18, 0.25], size=(ne, 3))
+    eo[:, 3:7] = [0, 0, 0, 1]
+    eo[:, 7:13] = rng3.normal(scale=0.1, size=(ne, 6))
+    shells = np.array([0.02, 0.045, 0.05, 0.055, 0.08, 0.1, 0.12, 0.3])
+    for k, (lo, vel, fin) in enumerate(((13, 16, 19), (21, 24, 27))):
+        d = rng3.normal(size=(ne, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r = shells[rng3.integers(0, shells.size, ne)] + rng3.uniform(-2e-3, 2e-3, ne)
+        eo[:, lo:lo + 3] = eo[:, 0:3] + d * np.abs(r)[:, None]
+        eo[:, vel:vel + 3] = rng3.normal(scale=0.1, size=(ne, 3))
+        eo[:, fin] = np.where(rng3.random(ne) < 0.9, rng3.uniform(0.0, 0.04, ne), rng3.uniform(0.2, 0.3, ne))
+        eo[:, fin + 1] = rng3.normal(scale=0.01, size=ne)
+    ea = np.array([np.asarray(cls.ezpolicy(SimpleNamespace(), {"observation": eo[i]}), dtype=np.float64) for i in range(ne)])
+    n1, n2 = np.linalg.norm(eo[:, 0:3] - eo[:, 13:16], axis=1), np.linalg.norm(eo[:, 0:3] - eo[:, 21:24], axis=1)
+    ig1, ig2 = (eo[:, 19] < 0.25) & (n1 < 0.05), (eo[:, 27] < 0.25) & (n2 < 0.05)
+    assert (~ig1).sum() > 50 and (ig1 & ~ig2).sum() > 50 and (ig1 & ig2).sum() > 20 and ((eo[:, 19] > 0.25) & (n1 < 0.05)).sum() > 3
+    out["ez_observation"], out["ez_action"] = eo, ea
     np.savez(os.path.join(OUT, "handover_reward_reference.npz"), **out)
     print("wrote handover_reward_reference.npz")
 

@@ -3,7 +3,7 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--workload pnp|reach|handover|stack|handover2]
                   [--scaling weak|strong] [--repeats R] [--episode-phase desync|lockstep] [--aged-preroll P]
-                  [--no-aged] [--no-lockstep] [--no-lazy] [--no-strong] [--no-extras] [--no-cpu-baseline]
+                  [--no-aged] [--no-lockstep] [--no-lazy] [--no-strong] [--no-extras] [--no-cpu-baseline] [--allow-variant-lib]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one env step of EVERY environment of the job (one xarm_step call per rank), including
@@ -18,7 +18,9 @@ the per-env step counters uniformly over the episode length before the warm-up, 
 their steady-state rate (E / max_episode_steps per step) instead of all E at once every 50th step; `lockstep` keeps the
 counters as reset() leaves them; the default `auto` picks the workload's own steady state - desync where an episode can
 end early by success (pnp, handover), lockstep where every episode has the same fixed length (reach, stack).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  `library` in it is xarm_version() and the path of the loaded libxarm_hip.so; a TIMING VARIANT
+(a development build with fewer solver sweeps) or a library named by XARM_HIP_LIB makes bench.py exit non-zero unless
+--allow-variant-lib says the run is a development measurement.
 
 Besides `value` (the K timed steps right after the W warm-up steps) the line carries, each measured by the same
 three-window protocol and never feeding `value`:
@@ -48,17 +50,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 6.
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CU x 4 SIMD x 16 lanes x 2 pk x 2 fma x 2.4 GHz), the bound that binds
 ALGO_BYTES_PER_ENV_STEP = 452  # SURVEY.md 8(d), PnP N=1: state in+out, action in, obs/goals/reward/flags out
 # workload -> (env id, default envs per GPU, action width, SURVEY 8(d) algorithmic bytes per env step, step kernel,
-#              oracle class, CPU-baseline sample (envs per thread, steps), config dict)
+#              oracle class, CPU-baseline sample (envs in total - BASELINE.md 3 asks for 4 096 - and steps), config dict)
 WORKLOADS = {
-    "pnp": ("XarmPDPickAndPlace-v0", 65536, 4, ALGO_BYTES_PER_ENV_STEP, "k_step", "OraclePnP", (128, 60),
+    "pnp": ("XarmPDPickAndPlace-v0", 65536, 4, ALGO_BYTES_PER_ENV_STEP, "k_step", "OraclePnP", (4096, 150),
             dict(GUI=False, num_obj=1, reward_type="sparse", init_grasp_rate=0.0, goal_ground_rate=0.0, goal_shape="air")),
-    "reach": ("XarmReach-v0", 4096, 4, 336, "k_reach_step", "OracleReach", (256, 100), None),
-    "handover": ("XarmPDHandover-v0", 16384, 8, 648, "k_ho_step", "OracleHandover", (16, 30),
+    "reach": ("XarmReach-v0", 4096, 4, 336, "k_reach_step", "OracleReach", (4096, 100), None),
+    "handover": ("XarmPDHandover-v0", 16384, 8, 648, "k_ho_step", "OracleHandover", (4096, 60),
                  dict(GUI=False, num_obj=1, same_side_rate=0.5, goal_shape="ground", use_stand=False)),
-    "stack": ("XarmPDStackTower-v0", 8192, 8, 1040, "k_st_step", "OracleStackTower", (64, 60), None),
+    "stack": ("XarmPDStackTower-v0", 8192, 8, 1040, "k_st_step", "OracleStackTower", (4096, 60), None),
     # not a BASELINE config: the reference's own test.py configuration (num_obj 2, goal_shape 'any'), same per-GPU size as
     # config 5; algorithmic bytes by SURVEY 8(d)'s rule: state (36 + 26 + 6 + 4 = 72 f) x 2 + action 32 B + out (42 + 6 + 6 + 3 = 57 f)
-    "handover2": ("XarmHandover-v0", 16384, 8, 836, "k_ho2_step", "OracleHandover", (16, 30),
+    "handover2": ("XarmHandover-v0", 16384, 8, 836, "k_ho2_step", "OracleHandover", (4096, 30),
                   dict(GUI=False, num_obj=2, same_side_rate=0.5, goal_shape="any", use_stand=False)),
 }
 
@@ -72,7 +74,8 @@ WORKLOAD_NAMES = {
     "stack": "XarmPDStackTower-v0 (XarmStackTowerEnv, three cubes, sparse reward; BASELINE config 4)",
     "handover2": "XarmHandover-v0 (XarmHandover, num_obj=2, goal_shape=any, same_side_rate=0.5: the reference's test.py:9-15; not a BASELINE config)",
 }
-SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15, "handover2": 15}   # internal substeps (Handover: 15 ticks of one substep)
+SUBSTEPS = {"pnp": 15, "reach": 20, "handover": 15, "stack": 15, "handover2": 15}   # internal substeps (Handover: 15 ticks of one substep);
+#                                                                                   the JSON line reports the library's own figure (xarm_dims)
 
 
 def reference_availability():
@@ -85,37 +88,32 @@ def reference_availability():
 
 
 def cpu_baseline(workload="pnp"):
-    """The CPU oracle (a restatement = kind "port"; PyBullet itself is absent) on the host cores:
-    every thread steps its own shard through ctypes (the GIL is released inside the C call)."""
+    """The CPU oracle (a restatement = kind "port"; PyBullet itself is absent) on the host cores.  BASELINE.md 3 sketches
+    "OpenMP over 4 096 envs"; what runs here is the same thing by other means: the 4 096 envs are split over `cores` Python
+    threads, each stepping its own oracle instance through ctypes (the GIL is released inside the C call; the oracle itself is
+    single-threaded C, gcc -O2, float64)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.lib()
-    env_id, _, act_dim, _, _, cls, (sample_envs_per_thread, steps), _ = WORKLOADS[workload]
+    env_id, _, act_dim, _, _, cls, (sample_envs, steps), _ = WORKLOADS[workload]
     cores = max(1, min(os.cpu_count() or 1, 16))
+    per = max(1, sample_envs // cores)
     okw = {"num_obj": 2, "goal_shape": "any"} if workload == "handover2" else {}
-    envs = [getattr(O, cls)(sample_envs_per_thread, seed=0, env_id_offset=k * sample_envs_per_thread, **okw) for k in range(cores)]
+    envs = [getattr(O, cls)(per, seed=0, env_id_offset=k * per, **okw) for k in range(cores)]
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, size=(steps, cores, sample_envs_per_thread, act_dim))
-
-    def work(k):
-        envs[k].reset()
-        t0 = time.perf_counter()
-        for s in range(steps):
-            envs[k].step(acts[s, k])
-        return time.perf_counter() - t0
+    acts = rng.uniform(-1, 1, size=(steps, cores, per, act_dim))
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        list(ex.map(work, range(cores)))
-        wall = time.perf_counter() - t0
-        # resets are outside the per-thread timers; redo the timed part alone for the rate
+        list(ex.map(lambda k: envs[k].reset(), range(cores)))
+        wall_reset = time.perf_counter() - t0
         t0 = time.perf_counter()
         list(ex.map(lambda k: [envs[k].step(acts[s, k]) for s in range(steps)], range(cores)))
         wall_steps = time.perf_counter() - t0
-    n = cores * sample_envs_per_thread * steps
+    n = cores * per * steps
     return {"value": n / wall_steps, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps of %s on the CPU oracle (float64, gcc -O2), %d threads, %.1f s"
-                      % (cores * sample_envs_per_thread, steps, env_id, cores, wall + wall_steps),
+            "sample": "%d envs x %d steps of %s on the CPU oracle (single-threaded C, float64, gcc -O2) split over %d Python threads through "
+                      "ctypes - not OpenMP; %.1f s of stepping + %.1f s of reset()" % (cores * per, steps, env_id, cores, wall_steps, wall_reset),
             "reference": reference_availability()}
 
 
@@ -161,6 +159,7 @@ def main():
     ap.add_argument("--aged-preroll", type=int, default=1000, help="untimed steps before the aged-state windows")
     ap.add_argument("--no-strong", action="store_true", help="world > 1: skip the strong-scaling leg")
     ap.add_argument("--no-extras", action="store_true", help="skip every leg that does not feed `value`")
+    ap.add_argument("--allow-variant-lib", action="store_true", help="development measurement: accept a TIMING VARIANT build / XARM_HIP_LIB")
     args = ap.parse_args()
     if args.no_extras:
         args.no_lazy = args.no_lockstep = args.no_aged = args.no_strong = True
@@ -215,16 +214,25 @@ def main():
     env.reset()
     T_ep = env.max_episode_steps
     env_state_dim = getattr(env, "state_dim", 0)
+    env_dims = type("Dims", (), {"n_substeps": getattr(env, "n_substeps", None)})
     env_out_floats = getattr(env, "obs_dim", 0) + 2 * getattr(env, "goal_dim", 0)
     # which kernel family this handle runs (include/xarm_hip.h xarm_kernel_limits): the cooperative kernels serve batches
     # / reset lists up to the limits, the one-env-per-lane kernels the rest
     reset_limit, step_limit = env.kernel_limits() if hasattr(env, "kernel_limits") else (0, 0)
+    # ... and which launches a step call is made of, from the handle itself (xarm_pipeline_info), with the library's identity
+    pipe = env.pipeline_info() if hasattr(env, "pipeline_info") else dict(fast_pipeline=False, reset_overlap=False, eject_coop_cap=0, solver_iterations=None)
+    lib_version, lib_path = env.library() if hasattr(env, "library") else ("stand-in env (no library)", None)
+    variant = "TIMING VARIANT" in lib_version or bool(os.environ.get("XARM_HIP_LIB"))
+    if variant and not args.allow_variant_lib:
+        raise SystemExit("bench.py: the loaded library is not the product build (%s, %s); pass --allow-variant-lib for a development measurement"
+                         % (lib_version, lib_path))
     if E <= step_limit and args.workload in COOP_STEP_KERNEL:
         kernel_name = COOP_STEP_KERNEL[args.workload]
-    elif args.workload == "pnp" and step_limit > 0 and os.environ.get("XARM_STEP_PIPELINE", "1") != "0":
-        # larger PickAndPlace batches: the pad-free fast kernel + the hand-off of the envs with finger-pad rows;
+    elif pipe["fast_pipeline"]:
+        # the pad-free fast kernel + the hand-off of the envs with finger-pad rows to the cooperative kernel;
         # the HIP events of the "step kernel" bracket both launches
-        kernel_name = "k_step_fast"
+        kernel_name = {"pnp": "k_step_fast", "handover": "k_ho_step_fast"}[args.workload]
+    handoff_kernel = {"k_step_fast": "k_step_coop_list", "k_ho_step_fast": "k_ho_step_coop_list"}.get(kernel_name)
     if args.episode_phase == "auto":
         # steady state of the workload: envs whose episodes can end early (success: PickAndPlace, Handover) drift apart
         # and reset at a uniform rate; fixed-length episodes (Reach: 25 steps, StackTower: 50, never `done` before)
@@ -386,6 +394,10 @@ def main():
                 tf_call = (flops * E + flops_reset * resets_per_call) / (call_ms * 1e-3) / 1e12
                 valu["reset_kernels"] = {"achieved": tf_reset, "frac": tf_reset / VALU_PEAK_TFLOPS, "counted_flops_per_env_reset": flops_reset,
                                          "resets_per_call": resets_per_call}
+                if pipe["reset_overlap"]:
+                    # the reset bracket is a residual (first launch on the side stream): no rate of the reset kernels alone
+                    valu["reset_kernels"] = {"counted_flops_per_env_reset": flops_reset, "resets_per_call": resets_per_call,
+                                             "note": "no rate: the reset time of a pipelined call is the residual after the hand-off"}
                 valu["achieved"], valu["frac"], valu["covers"] = tf_call, tf_call / VALU_PEAK_TFLOPS, "step + reset kernels of one xarm_step call"
             else:
                 valu["achieved"], valu["frac"], valu["covers"] = tf_step, tf_step / VALU_PEAK_TFLOPS, "step kernel only (reset flops not counted for this workload)"
@@ -395,20 +407,26 @@ def main():
             tf = n_valu * 64 * 2 / (kstep_ms * 1e-3) / 1e12
             valu = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (<=2 flop per lane-instruction, step kernel only)",
                     "frac": tf / VALU_PEAK_TFLOPS, "wave_insts_per_launch": n_valu, "covers": "step kernel only"}
+        ho_reset = "k_ho_reset_coop" if reset_limit > 0 else "k_ho_reset"
         reset_kernel_key = {"pnp": "k_reset_coop", "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
-                            "handover": "k_ho_reset", "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
+                            "handover": ho_reset, "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
         reset_kernel = {"pnp": "k_reset_coop (<= %d finished envs per call) / k_reset" % reset_limit,
                         "reach": "k_reach_reset_coop" if E <= reset_limit else "k_reach_reset",
-                        "handover": "k_ho_reset", "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
+                        "handover": ho_reset + (" (<= %d finished envs per call) / k_ho_reset" % reset_limit if reset_limit > 0 else ""),
+                        "stack": "k_st_reset", "handover2": "k_ho2_reset"}[args.workload]
         # reset kernels: algorithmic bytes = state in + out and the fresh obs / goal rows, per finished env
         reset_algo = resets_per_call * (2 * 4 * env_state_dim + 4 * env_out_floats)
         reset_traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (reset_kernel_key, E))
         reset_entry = {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms, "resets_per_call": resets_per_call,
                        "algorithmic_bytes_per_launch": reset_algo, "traffic": reset_traffic}
-        if kernel_name == "k_step_fast":
+        reset_entry["avg_ms_is"] = "reset kernels, on the caller's stream after the step kernel(s)"
+        if pipe["reset_overlap"]:
+            # the first reset launch runs on the handle's side stream beside the hand-off: the bracket holds what is LEFT of the resets
+            # after the hand-off, so step + reset no longer partitions the kernels' own time and no rate is derived from it
+            reset_entry["avg_ms_is"] = "residual after the hand-off (the first reset launch overlaps it on a side stream; the join is inside the bracket)"
             reset_entry["note"] = ("two launches per call: the episodes that ended in k_step_fast are reset on a side stream while the hand-off "
-                                   "runs, those that ended in the hand-off after it; avg_ms = what is left of both after the hand-off (DESIGN.md 4b)")
-        if reset_ms > 0:
+                                   "runs, those that ended in the hand-off after it (DESIGN.md 4b)")
+        elif reset_ms > 0:
             reset_entry["achieved_GBs"] = reset_algo / (reset_ms * 1e-3) / 1e9
             reset_entry["frac"] = reset_entry["achieved_GBs"] / HBM_PEAK_GBS
         out = {
@@ -416,7 +434,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAMES[args.workload],
-                       "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": SUBSTEPS[args.workload], "solver_iterations": 50,
+                       "envs_per_gpu": E, "total_envs": total_envs, "substeps_per_step": getattr(env_dims, "n_substeps", None) or SUBSTEPS[args.workload],
+                       "solver_iterations": pipe["solver_iterations"],
                        "auto_reset": True, "episode_phase": args.episode_phase, "episodes_reset_in_window": int(resets),
                        "resets_per_step": resets / args.steps, "steady_state_time_limit_resets_per_step": total_envs / T_ep,
                        "parallelism": "env-shard x%d, no collective" % world},
@@ -430,7 +449,7 @@ def main():
             # achieved / peak / frac / traffic are the HBM figures the contract asks for - a fused step touches HBM once
             "roofline": {"bound": "valu/latency", "reported_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "%s + %s (one xarm_step call)" % (kernel_name + (" + k_step_coop_list (hand-off)" if kernel_name == "k_step_fast" else
+                         "kernel": "%s + %s (one xarm_step call)" % (kernel_name + (" + %s (hand-off)" % handoff_kernel if handoff_kernel else
                                                                                    " (+ k_class_hist, k_class_place: class order)" if kernel_name == "k_st_step" else ""), reset_kernel),
                          "kernel_avg_ms": call_ms, "kernel_launches": int(launches),
                          "algorithmic_bytes_per_launch": algo_bytes,
@@ -441,6 +460,8 @@ def main():
                          "note": "fused step: HBM is touched once per env step, the kernels are fp32-VALU/latency bound (DESIGN.md 5); "
                                  "`traffic` is the PMC figure of the step kernel, kernels.reset.traffic that of the reset kernel"},
             "kernel_only_env_steps_per_sec_per_gpu": E / (call_ms * 1e-3),
+            "library": {"version": lib_version, "path": lib_path, "variant": variant, "pipeline": pipe,
+                        "reset_coop_limit": reset_limit, "step_coop_limit": step_limit},
         }
         if valu is not None:
             out["roofline"]["valu"] = valu

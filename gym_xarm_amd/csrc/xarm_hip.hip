@@ -227,6 +227,9 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         h->ho_force_coupled = ev && *ev && atoi(ev) != 0;
     }
     h->kp.eject_coop_cap = handover1 ? XARM_HO_EJECT_COOP_CAP : XARM_EJECT_COOP_CAP;
+    // step_coop_limit == 1 is the pin of reproducible_limits('fast'): every hand-off list steps on the cooperative kernel (it
+    // walks the list with a grid stride), so that which kernel steps an env is a function of the handle's config alone
+    if (cfg->step_coop_limit == 1) h->kp.eject_coop_cap = 0x7fffffff;
     h->kp.state_dim = reach ? xr::STATE_DIM : (handover2 ? xh2::STATE_DIM : (handover ? xh::STATE_DIM : (stack ? xs::STATE_DIM : xk::STATE_DIM)));
     h->kp.hcfg.seed = cfg->seed;
     h->kp.hcfg.env_id_offset = cfg->env_id_offset;
@@ -585,6 +588,20 @@ int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t 
     if (!h || !reset_coop_limit || !step_coop_limit) return XARM_E_INVALID;
     *reset_coop_limit = h->kp.coop_limit;
     *step_coop_limit = h->coop_step_limit;
+    return XARM_OK;
+}
+int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
+                       int32_t *solver_iterations) {
+    if (!h || !fast_pipeline || !reset_overlap || !eject_coop_cap || !solver_iterations) return XARM_E_INVALID;
+    const bool small = (h->cfg.env_kind == XARM_ENV_PICK_AND_PLACE || h->cfg.env_kind == XARM_ENV_REACH) && h->kp.num_envs <= (int64_t)h->coop_step_limit;
+    *fast_pipeline = (h->fast_pipeline && !small) ? 1 : 0;
+    *reset_overlap = (*fast_pipeline && h->reset_overlap) ? 1 : 0;
+    *eject_coop_cap = h->kp.eject_coop_cap;
+#if defined(XARM_SWEEP_VARIANT)
+    *solver_iterations = XARM_SWEEP_VARIANT;
+#else
+    *solver_iterations = xm::NUM_ITERATIONS;
+#endif
     return XARM_OK;
 }
 

@@ -87,6 +87,7 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, self._L.xarm_dims(self._h, C.byref(d)), "xarm_dims")
         self.obs_dim, self.goal_dim, self.act_dim, self.state_dim = d.obs_dim, d.goal_dim, d.act_dim, d.state_dim
         self._max_episode_steps = d.max_episode_steps
+        self.n_substeps = d.n_substeps          # internal substeps (Handover: stepSimulation calls) per env step
         self.distance_threshold = 0.05
         E, dev = self.num_envs, self.device
         f32 = torch.float32
@@ -279,6 +280,17 @@ class XarmPickAndPlaceVecEnv:
         r, s = C.c_int32(0), C.c_int32(0)
         _native.check(self._L, self._h, self._L.xarm_kernel_limits(self._h, C.byref(r), C.byref(s)), "xarm_kernel_limits")
         return r.value, s.value
+
+    def pipeline_info(self):
+        """which launches a step() call is made of and the solver constants the library was built with (include/xarm_hip.h
+        xarm_pipeline_info): dict(fast_pipeline, reset_overlap, eject_coop_cap, solver_iterations)"""
+        v = [C.c_int32(0) for _ in range(4)]
+        _native.check(self._L, self._h, self._L.xarm_pipeline_info(self._h, *[C.byref(x) for x in v]), "xarm_pipeline_info")
+        return dict(fast_pipeline=bool(v[0].value), reset_overlap=bool(v[1].value), eject_coop_cap=v[2].value, solver_iterations=v[3].value)
+
+    def library(self):
+        """(xarm_version(), path of the loaded libxarm_hip.so)"""
+        return self._L.xarm_version().decode(), _native.loaded_path()
 
     def class_keys(self):
         """uint8 [E] (StackTower): the row-set class of every env's last substep - what the step kernel groups the envs by

@@ -155,12 +155,31 @@ int xarm_debug_substeps(xarm_handle *h, const float *qtarget_dev, int32_t n, voi
 /* optional kernel timing: HIP events recorded around the step kernel on the caller's stream */
 int xarm_timing_enable(xarm_handle *h, int32_t enable);
 int xarm_timing_read(xarm_handle *h, double *step_kernel_ms_total, int64_t *launches);
-/* same for the reset kernels that follow the step kernel inside xarm_step (auto_reset): total ms over `launches` calls */
+/* same for what follows the step kernel(s) on the caller's stream inside xarm_step (auto_reset): the reset kernels - and,
+ * for a pipelined PickAndPlace call, only what is LEFT of them after the hand-off (the first reset launch runs on the
+ * handle's side stream beside the hand-off; the join is inside this bracket).  Total ms over `launches` calls */
 int xarm_timing_read_reset(xarm_handle *h, double *reset_kernels_ms_total, int64_t *launches);
 
 /* the limits in force for this handle.  Precedence: an explicit xarm_config value (> 0, or < 0 = never) wins; with the
  * field at 0 the XARM_RESET_COOP_LIMIT / XARM_STEP_COOP_LIMIT environment variable replaces the built-in default: batches / reset lists of at most that many envs run on the cooperative kernels (0: never) */
 int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t *step_coop_limit);
+
+/* which launches an xarm_step call of this handle is made of (what bench.py names the kernels from, instead of re-deriving it
+ * from environment variables) and the solver constants the library was BUILT with:
+ *   fast_pipeline    1: the pad-free fast step + the hand-off of the envs with an active finger-pad row to the cooperative
+ *                    kernel (PickAndPlace batches above step_coop_limit, XarmHandover with one stick at every batch size);
+ *                    0: one step kernel (the cooperative one for batches of at most step_coop_limit envs).  Only
+ *                    step_coop_limit < 0 or XARM_STEP_PIPELINE=0 turn the pipeline off - XARM_STEP_COOP_LIMIT=0 turns off
+ *                    the cooperative STEP kernel of small batches, not the pipeline of large ones
+ *   reset_overlap    1: PickAndPlace pipeline with the first reset launch on the handle's side stream (XARM_RESET_OVERLAP)
+ *   eject_coop_cap   hand-off lists of at most this many envs step on the cooperative kernel, longer ones on the
+ *                    one-env-per-lane kernel; INT32_MAX when step_coop_limit == 1 (the pin of
+ *                    gym_xarm_amd.distributed.reproducible_limits('fast'): the choice is then a function of the config alone)
+ *   solver_iterations  Gauss-Seidel sweeps per substep compiled into the kernels (50 = Bullet's numSolverIterations; a
+ *                    timing variant built with -DXC_SWEEP_ITERS / -DXK_SWEEP_ITERS reports its own value and
+ *                    xarm_version() says "TIMING VARIANT") */
+int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
+                       int32_t *solver_iterations);
 
 /* StackTower: the row-set class each env's last substep fell into, uint8 [E] (bits 0-2 cube pairs (0,1) (0,2) (1,2) in
  * contact, bit 3 / 4 a finger pad of arm 0 / 1 active).  The step

@@ -44,6 +44,12 @@ class StubEnv:
     def timing_read_reset(self):
         return 0.25 * (self.n_step - self._t0), self.n_step - self._t0
 
+    def pipeline_info(self):
+        return dict(fast_pipeline=False, reset_overlap=False, eject_coop_cap=0, solver_iterations=50)
+
+    def library(self):
+        return "stand-in env (tests/bench_stub.py)", None
+
     def close(self):
         pass
 

@@ -22,28 +22,35 @@ def reproducible_limits(total_envs, family=None):
     """Kernel-family pins (`reset_coop_limit`, `step_coop_limit` of xarm_config / make()) that make a shard's result
     BITWISE independent of the world size.
 
-    By default a handle picks its kernels from its OWN batch size (include/xarm_hip.h: batches / reset lists of at most
-    8 192 envs run on the cooperative 16-lanes-per-env kernels), so the 8 192-env shard of a 65 536-env job on 8 GPUs
-    steps on k_step_coop while the same envs on one GPU step on k_step - the two agree to float32 rounding, and contact
-    chaos then separates the trajectories.  With these limits passed to EVERY shard (and to the single-GPU run) all of
-    them use one family, chosen from the TOTAL env count:
-      family 'lane' (default when total_envs > 8 192): (-1, -1), the one-env-per-lane kernels everywhere - what a single
-          GPU runs for the step at that size; resets then cost six ticks of a lone wavefront (slow: the price of the pin);
+    By default a handle picks its kernels from its OWN batch size and from COUNTS (include/xarm_hip.h: batches / reset
+    lists of at most 8 192 envs run on the cooperative 16-lanes-per-env kernels, hand-off lists of more than
+    XARM_EJECT_COOP_CAP envs on the one-env-per-lane kernel), so the 8 192-env shard of a 65 536-env job on 8 GPUs steps on
+    k_step_coop while the same envs on one GPU step on the fast pipeline - the two agree to float32 rounding, and contact
+    chaos then separates the trajectories.  With these limits passed to EVERY shard (and to the single-GPU run) which kernel
+    handles an env is a function of the env's own state and of the job's config, never of a shard's size or of a count:
+      family 'fast' (default when total_envs > 8 192): (total_envs, 1) - the fast pipeline at every shard size (pad-free
+          fast step, every hand-off on the cooperative kernel) and the cooperative reset for every reset list.  The speed
+          of the default choice at the BASELINE sizes, within a few per cent; a bulk reset() of a large batch is slower
+          (cooperative kernel on every env);
+      family 'lane': (-1, -1), the one-env-per-lane kernels everywhere; resets then cost six ticks of a lone wavefront
+          (~3x slower per step call: the price of that pin);
       family 'coop' (default otherwise): (total_envs, total_envs), the cooperative kernels everywhere.
     Speed, not semantics, depends on the choice (tests/test_gpu_parity.py::test_world_size_invariance_at_the_baseline_split)."""
     from ._native import RESET_COOP_LIMIT_DEFAULT
     if family is None:
-        family = "lane" if int(total_envs) > RESET_COOP_LIMIT_DEFAULT else "coop"
+        family = "fast" if int(total_envs) > RESET_COOP_LIMIT_DEFAULT else "coop"
+    if family == "fast":
+        return {"reset_coop_limit": int(total_envs), "step_coop_limit": 1}
     if family == "lane":
         return {"reset_coop_limit": -1, "step_coop_limit": -1}
     if family == "coop":
         return {"reset_coop_limit": int(total_envs), "step_coop_limit": int(total_envs)}
-    raise ValueError("family must be 'lane' or 'coop'")
+    raise ValueError("family must be 'fast', 'lane' or 'coop'")
 
 
 def make_shard(env_id, total_envs, rank=None, world_size=None, reproducible=False, **kwargs):
     """This rank's shard of a `total_envs` job: gym_xarm_amd.make with num_envs / env_id_offset from shard_range.
-    reproducible=True (or 'lane' / 'coop') adds reproducible_limits(total_envs): bitwise the same per-env results at
+    reproducible=True (or 'fast' / 'lane' / 'coop') adds reproducible_limits(total_envs): bitwise the same per-env results at
     every world size, at the cost of the per-shard kernel choice."""
     import gym_xarm_amd
     r, _, w = env_from_torchrun()

@@ -322,6 +322,55 @@ class OracleTorchEnv:
         return self.torch.tensor(self.ora.get_state(), dtype=self.torch.float32)
 
 
+class ShardedOracleHandover:
+    """W OracleHandover instances on W threads (ctypes releases the GIL): the live fixtures of the Handover GPU tests cost
+    ~65 000 oracle env steps each"""
+
+    def __init__(self, oracle, E, W=8, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        assert E % W == 0
+        self.n, self.W = E // W, W
+        self.o = [oracle.OracleHandover(self.n, env_id_offset=k * self.n, **kw) for k in range(W)]
+        self.ex = ThreadPoolExecutor(W)
+
+    def _map(self, fn):
+        return list(self.ex.map(fn, range(self.W)))
+
+    def reset(self):
+        return np.concatenate([r[0] for r in self._map(lambda k: self.o[k].reset())])
+
+    def get_state(self):
+        return np.concatenate([o.get_state() for o in self.o])
+
+    def step_from(self, st, a):
+        """(outputs of step, next state) from the injected state"""
+        def run(k):
+            sl = slice(k * self.n, (k + 1) * self.n)
+            self.o[k].set_state(st[sl])
+            out = self.o[k].step(a[sl])
+            return out, self.o[k].get_state()
+        r = self._map(run)
+        return [np.concatenate([x[0][i] for x in r]) for i in range(6)], np.concatenate([x[1] for x in r])
+
+    def sens(self, st, a, nxt, cont, quats, seed, draws=(1e-6, 1e-6, 1e-6, 1e-7, 1e-7, 1e-7)):
+        """the oracle's own response to a perturbation of the input state, per env.  Six draws at two amplitudes: a stick held
+        by sliding pads answers a 1e-7 perturbation with 0.2 in float64 on transitions where two draws at 1e-6 saw 3e-3
+        (tests/tools/ho_outliers.py) - the probe has to sample the contact discontinuities it is there to detect"""
+        sens = np.zeros(st.shape[0])
+        for j, eps in enumerate(draws):
+            sp = st.copy()
+            sp[:, cont] += np.random.default_rng(100 * seed + j).uniform(-eps, eps, size=(st.shape[0], cont.size))
+            for q in quats:
+                sp[:, q] /= np.linalg.norm(sp[:, q], axis=1, keepdims=True)
+            sens = np.maximum(sens, np.abs(self.step_from(sp, a)[1][:, cont] - nxt[:, cont]).max(axis=1))
+        return sens
+
+
+@pytest.fixture(scope="session")
+def sharded_handover():
+    return ShardedOracleHandover
+
+
 @pytest.fixture(scope="session")
 def oracle_torch_env():
     return OracleTorchEnv

@@ -164,3 +164,14 @@ def test_register_with_gym_mirrors_registry(monkeypatch):
     assert got["XarmHandover-v0"][1:] == ("gym_xarm_amd.envs:XarmHandover", 100)
     assert got["XarmPickAndPlace-v1"][1:] == ("gym_xarm_amd.envs:XarmPickAndPlace", 50)
     assert set(got) == set(gym_xarm_amd.registered_ids())
+
+
+def test_reproducible_limits_are_functions_of_the_job_config():
+    """the pins of gym_xarm_amd.distributed.reproducible_limits: 'fast' (default above 8 192 envs) = the fast pipeline at every
+    shard size + the cooperative reset for every list; every shard of a job gets the same pair"""
+    from gym_xarm_amd import distributed as D
+    assert D.reproducible_limits(65536) == D.reproducible_limits(65536, "fast") == {"reset_coop_limit": 65536, "step_coop_limit": 1}
+    assert D.reproducible_limits(65536, "lane") == {"reset_coop_limit": -1, "step_coop_limit": -1}
+    assert D.reproducible_limits(4096) == D.reproducible_limits(4096, "coop") == {"reset_coop_limit": 4096, "step_coop_limit": 4096}
+    with pytest.raises(ValueError):
+        D.reproducible_limits(10, "warp")

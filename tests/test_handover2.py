@@ -263,6 +263,56 @@ def test_gpu_handover2_replays_golden_rollout(groll, parity):
 
 
 @pytest.mark.gpu
+def test_gpu_handover2_live_oracle_256_envs(oracle, sharded_handover):
+    """a live-oracle step test on 256 envs for the two-stick kernel - the three scripted scenes of the
+    rollout fixture with per-env jitter (crossed sticks under random arm motion, ezpolicy dragging stick 0 against stick 1,
+    ezpolicy on stick 1), every transition replayed on the device from the oracle's state.  Achieved on MI355X (printed):
+    the share of envs inside the plain 5e-4 + 2e-4 |x| bound and the exempt share, per step."""
+    import sys
+    import torch
+    import gym_xarm_amd as gx
+    from oracle import parity
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from gen_oracle_fixtures import JitteredHandover2, ho2_scene
+    E = 264      # 11 x 24: whole groups of the three scenes
+    ora = sharded_handover(oracle, E, 8, seed=41, num_obj=2, goal_shape="any")
+    ora.reset()
+    st = ho2_scene(ora.get_state(), np.random.default_rng(12))
+    out, st = ora.step_from(st, np.zeros((E, 8)))      # one quiet step: the scripted scenes settle their contact impulses
+    obs = out[0]
+    cfg = {"GUI": False, "num_obj": 2, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": False}
+    env = gx.make("XarmHandover-v0", num_envs=E, seed=41, auto_reset=False, config=cfg)
+    pol = JitteredHandover2(E, seed=6)
+    quats = [slice(44, 48), slice(48, 52)]
+    worst_tight, worst_exempt, n_contact, n_contact_tight, n_pair, n_flag, n_ok = 1.0, 0.0, 0, 0, 0, 0, 0
+    for t in range(pol.horizon):
+        a = pol(obs, t)
+        o, nxt = ora.step_from(st, a)
+        sens = ora.sens(st, a, nxt, CONT, quats, t)
+        env.set_state(st)
+        dobs, rew, done, info = env.step(torch.tensor(a, dtype=torch.float32))
+        dev = env.get_state().cpu().numpy().astype(np.float64)
+        stats = parity.compare(dev[:, CONT], nxt[:, CONT], sens, what="handover2 live t=%d" % t, frac_tight=0.9, max_exempt=0.15)   # 0.909 / 0.133 on MI355X
+        worst_tight, worst_exempt = min(worst_tight, stats["frac_tight"]), max(worst_exempt, stats["frac_exempt"])
+        contact = ((np.abs(nxt[:, LP]) > 0).any(axis=1) | (nxt[:, TOUCH] > 0).any(axis=1)) & (sens <= parity.SENS_EXEMPT)
+        err = np.abs(dev[:, CONT] - nxt[:, CONT])
+        tight = (err <= parity.ATOL + parity.RTOL * np.abs(nxt[:, CONT])).all(axis=1)
+        n_contact += contact.sum()
+        n_contact_tight += (contact & tight).sum()
+        n_pair += (np.linalg.norm(nxt[:, BP0] - nxt[:, BP1], axis=1) < 0.08).sum()       # sticks close enough to touch
+        ok = sens < 1e-3
+        assert np.array_equal(rew.cpu().numpy()[ok], o[3][ok].astype(np.float32)) and np.array_equal(done.cpu().numpy()[ok], o[4][ok])
+        n_flag += (dev[ok][:, TOUCH] == nxt[ok][:, TOUCH]).all(axis=1).sum()
+        n_ok += ok.sum()
+        st, obs = nxt, o[0]
+    print("handover2 live oracle: worst frac_tight %.3f, worst frac_exempt %.3f, pad-contact rows %d (%.3f tight), stick/stick rows %d"
+          % (worst_tight, worst_exempt, n_contact, n_contact_tight / max(n_contact, 1), n_pair))
+    assert n_contact > 800 and n_contact_tight >= 0.85 * n_contact and n_pair > 2000
+    assert n_flag >= 0.98 * n_ok
+    env.close()
+
+
+@pytest.mark.gpu
 def test_gpu_handover2_reset_sampling_and_properties(oracle, gref):
     """4 096 envs through the C ABI: the device's rejection sampling obeys the reference's spacing rules and equals the
     oracle's draws; determinism, shard invariance, auto-reset, invariants, batched compute_reward"""

@@ -114,57 +114,23 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-class _Sharded:
-    """W oracles on W threads (ctypes releases the GIL): the live fixture costs ~65 000 oracle env steps"""
-
-    def __init__(self, oracle, E, W, **kw):
-        from concurrent.futures import ThreadPoolExecutor
-        assert E % W == 0
-        self.n, self.W = E // W, W
-        self.o = [oracle.OracleHandover(self.n, env_id_offset=k * self.n, **kw) for k in range(W)]
-        self.ex = ThreadPoolExecutor(W)
-
-    def _map(self, fn):
-        return list(self.ex.map(fn, range(self.W)))
-
-    def reset(self):
-        return np.concatenate([r[0] for r in self._map(lambda k: self.o[k].reset())])
-
-    def step_from(self, st, a):
-        """(outputs of step, next state) from the injected state"""
-        def run(k):
-            sl = slice(k * self.n, (k + 1) * self.n)
-            self.o[k].set_state(st[sl])
-            out = self.o[k].step(a[sl])
-            return out, self.o[k].get_state()
-        r = self._map(run)
-        return [np.concatenate([x[0][i] for x in r]) for i in range(6)], np.concatenate([x[1] for x in r])
-
-
 @pytest.fixture(scope="module")
-def live(oracle):
+def live(oracle, sharded_handover):
     """256 envs under the reference's ezpolicy with per-env jitter (tests/tools/gen_oracle_fixtures.JitteredHandover): per step
-    the oracle's state, action, outputs, next state and its own sensitivity.  Six perturbation draws at two amplitudes: a
-    stick held by sliding pads answers a 1e-7 perturbation with 0.2 in float64 on transitions where two draws at 1e-6 saw
-    3e-3 (tests/tools/ho_outliers.py) - the probe has to sample the contact discontinuities it is there to detect."""
+    the oracle's state, action, outputs, next state and its own sensitivity (six perturbation draws at two amplitudes,
+    tests/conftest.py ShardedOracleHandover.sens)"""
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     from gen_oracle_fixtures import JitteredHandover
     E = 256
-    ora = _Sharded(oracle, E, 8, seed=31)
+    ora = sharded_handover(oracle, E, 8, seed=31)
     obs = ora.reset()
-    st = np.concatenate([o.get_state() for o in ora.o])
+    st = ora.get_state()
     pol = JitteredHandover(E, seed=4)
     rows = []
     for t in range(pol.horizon):
         a = pol(obs, t)
         out, nxt = ora.step_from(st, a)
-        sens = np.zeros(E)
-        for j, eps in enumerate((1e-6, 1e-6, 1e-6, 1e-7, 1e-7, 1e-7)):
-            sp = st.copy()
-            sp[:, CONT] += np.random.default_rng(100 * t + j).uniform(-eps, eps, size=(E, CONT.size))
-            sp[:, 41:45] /= np.linalg.norm(sp[:, 41:45], axis=1, keepdims=True)
-            sens = np.maximum(sens, np.abs(ora.step_from(sp, a)[1][:, CONT] - nxt[:, CONT]).max(axis=1))
-        rows.append((st, a, out, nxt, sens))
+        rows.append((st, a, out, nxt, ora.sens(st, a, nxt, CONT, [slice(41, 45)], t)))
         st, obs = nxt, out[0]
     return rows
 

@@ -29,6 +29,7 @@ def test_oracle_free_spin_does_not_gain_energy(oracle):
     ("XarmPDPickAndPlace-v0", 2048, 4, 100, dict(init_grasp_rate=1.0, reward_type="dense", goal_shape="ground")),
     ("XarmReach-v0", 4096, 4, 60, None),
     ("XarmPDHandover-v0", 2048, 8, 120, None),
+    ("XarmHandover-v0", 2048, 8, 120, dict(GUI=False, num_obj=2, same_side_rate=0.5, goal_shape="any", use_stand=False)),   # the reference's test.py config
     ("XarmPDStackTower-v0", 2048, 8, 110, None),
 ])
 def test_long_hostile_rollouts_stay_finite(env_id, E, A, steps, cfg):

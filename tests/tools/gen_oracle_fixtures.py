@@ -243,6 +243,50 @@ def ho2_sens(ora, s0, a, nxt, seed):
     return sens
 
 
+def ho2_scene(st, rng):
+    """the three scripted two-stick scenes of the rollout fixture, env e in group (e % 24) // 8, with per-env jitter: stick 1
+    laid across stick 0; the sticks side by side and touching on arm 1's side; the sticks far apart (stick 1 on arm 1's side)"""
+    for e in range(st.shape[0]):
+        j = rng.uniform(-1, 1, 4)
+        grp = (e % 24) // 8
+        if grp == 0:
+            st[e, 38:41] = [-0.19 + 0.03 * j[0], 0.05 * j[1], 0.025]
+            st[e, 41:44] = [st[e, 38] + 0.03 * j[2], st[e, 39] + 0.012 * j[3], 0.0752]
+        elif grp == 1:
+            st[e, 38:41] = [-0.2 + 0.03 * j[0], 0.04 * j[1], 0.025]
+            st[e, 41:44] = [st[e, 38] + 0.02 * j[2], st[e, 39] + (0.05 + 0.001 * j[3]) * (1 if e % 2 else -1), 0.025]
+        else:
+            st[e, 38:41] = [0.2 + 0.03 * j[0], 0.1 * j[1], 0.025]
+            st[e, 41:44] = [-0.2 + 0.03 * j[2], 0.05 * j[3], 0.025]
+        st[e, 44:52] = [0, 0, 0, 1, 0, 0, 0, 1]
+        st[e, 52:64] = 0
+        st[e, 70:94] = 0
+    return st
+
+
+class JitteredHandover2:
+    """closed-loop policy of the two-stick live fixture (tests/test_handover2.py): group 0 small random arm motion over the
+    crossed sticks, group 1 the reference's ezpolicy steering at stick 0 (dragging it against stick 1), group 2 ezpolicy
+    steering at stick 1; per-env start delay, steering bias and action noise"""
+
+    def __init__(self, E, seed=0, horizon=34):
+        rng = np.random.default_rng(seed)
+        self.delay = rng.integers(0, 5, E)
+        self.bias = rng.uniform(-0.12, 0.12, (E, 8))
+        self.bias[:, [3, 7]] = 0.0
+        self.rng, self.horizon = rng, horizon
+
+    def __call__(self, obs, t):
+        E = obs.shape[0]
+        a = np.zeros((E, 8))
+        for e in range(E):
+            grp = (e % 24) // 8
+            a[e] = self.rng.uniform(-0.3, 0.3, 8) if grp == 0 else _ez_on(obs[e], 0 if grp == 1 else 1)
+        a += self.bias + self.rng.uniform(-0.1, 0.1, (E, 8)) * np.array([1, 1, 1, 0, 1, 1, 1, 0])
+        a[t < self.delay] = 0.0
+        return np.clip(a, -1, 1)
+
+
 def handover2():
     """XarmHandover-v0 with num_obj = 2 (the reference's test.py configuration): 24 envs, 30 scripted + 6 random steps.
     Envs 0-7: stick 1 laid across the top of stick 0 (stick/stick manifold under load) with small random arm motion;

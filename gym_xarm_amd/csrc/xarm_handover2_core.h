@@ -1,7 +1,7 @@
 // xarm_handover2_core.h - XarmHandover-v0 with config['num_obj'] = 2: two xarm7_pd arms (one lane each) and two sticks.
 //
 // This is the configuration of the reference's only test (/root/reference/test.py:9-15: num_obj 2, goal_shape 'any',
-// same_side_rate 0.5, use_stand False) and of the env file's own __main__ (xarm_handover.py:448-455).
+// same_side_rate 0.5, use_stand False) and of the env file's own __main__ (xarm_handover.py:448-455); use_stand True: Scene below.
 // Reference: /root/reference/gym_xarm/envs/xarm_handover.py
 //   lane_step  = XarmHandover.step :128-139 (+ _set_action :244-297: grasp flags / friction toggle from contacts with
 //                legos[0] only :263-280, the clamp loop over every stick :282-297; _get_obs :299-336, obs 13 N + 16 = 42)
@@ -55,7 +55,10 @@ template <typename T> XARM_HD V3<T> ldv(const T (&a)[3]) { return mk<T>(a[0], a[
 
 // ---------------------------------------------------------------------------------------------
 // one p.stepSimulation() at timeStep 1/240 (no internal substeps, :28-29,131-132)
-template <typename T, typename Lds, typename Xchg>
+// Scene = xh::HandoverStandScene (config['use_stand'], :391-392): one static stand per goal; every stick's most downward face
+// against the top of EITHER stand gives up to four more candidates of that stick's <= 4 point support manifold, after its
+// corners, stand 0 before stand 1 (ids 8..15, no warm start) - the one-stick stand model per (stick, stand) pair.
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const Xchg xchg) {
     const T dt = (T)xm::HO_TIME_STEP;
     const T idt = (T)1 / dt;
@@ -152,6 +155,36 @@ XARM_HD void substep(Lane<T> &L, const T (&qt)[9], Lds lds, const int arm, const
                 vb[o] = vb[o] + fi * imb;
                 wb[o] = wb[o] + symmul(Iinv[o], cross(r, fi));
                 cnt++;
+            }
+        }
+        if constexpr (Scene::HAS_STAND) {
+#pragma unroll
+            for (int j = 0; j < NOBJ; j++) {
+                V3<T> sp[4];
+                T sd[4];
+                Scene::template stand_points<T>(L.goal[j], cb[o], Rb[o][0], Rb[o][1], Rb[o][2], sp, sd);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const T dist = sd[v];
+                    const bool act = dist < (T)xm::SOLVER_MARGIN && dist > (T)Scene::STAND_MIN_GAP && cnt < 4;
+                    if (act) {
+                        const int base = LDS_TP + (o * 4 + cnt) * TP_W;
+                        const V3<T> r = sp[v] - cb[o];
+                        const V3<T> cx = mk<T>((T)0, r.z, -r.y), cy = mk<T>(-r.z, (T)0, r.x), cz = mk<T>(r.y, -r.x, (T)0);
+                        const V3<T> wx = symmul(Iinv[o], cx), wy = symmul(Iinv[o], cy), wz = symmul(Iinv[o], cz);
+                        const T K0 = imb + dot(cx, wx), K3 = imb + dot(cy, wy), K5 = imb + dot(cz, wz);
+                        lds[base + 0] = r.x; lds[base + 1] = r.y; lds[base + 2] = r.z;
+                        lds[base + 3] = (T)0; lds[base + 4] = (T)0; lds[base + 5] = (T)0;
+                        lds[base + 6] = dist < (T)0 ? -(T)xm::CONTACT_ERP * dist * idt : -dist * idt;
+                        lds[base + 7] = dot(cx, wy); lds[base + 8] = dot(cx, wz); lds[base + 9] = K3;
+                        lds[base + 10] = dot(cy, wz); lds[base + 11] = K5;
+                        lds[base + 12] = (T)1 / K5;
+                        lds[base + 13] = (T)1 / K3;
+                        lds[base + 14] = (T)1 / K0;
+                        lds[base + 15] = (T)(8 + 4 * j + v);
+                        cnt++;
+                    }
+                }
             }
         }
     }
@@ -781,7 +814,7 @@ template <typename T> XARM_HD void lane_init(const EnvCfg &cfg, int64_t env, Lan
     sample_object(cfg, env, 0, L);
     sample_goal(cfg, env, 0, L);
 }
-template <typename T, typename Lds, typename Xchg>
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds lds, Xchg x) {
     const int64_t episode = (int64_t)L.episode + 1;
     T qt[9];
@@ -791,14 +824,14 @@ XARM_HD void lane_reset(const EnvCfg &cfg, int64_t env, Lane<T> &L, int arm, Lds
     for (int k = 0; k <= xm::HO_RESET_TICKS; k++) {
         if (k < xm::HO_RESET_TICKS) ik(L, arm, home, qt);
         else sample_object(cfg, env, episode, L);
-        substep<T, Lds, Xchg>(L, qt, lds, arm, x);
+        substep<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
     }
     sample_goal(cfg, env, episode, L);
     L.steps = (T)0;
     L.episode = (T)episode;
 }
 // act = this arm's 4 action entries (:249-256)
-template <typename T, typename Lds, typename Xchg>
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x) {
     L.steps += (T)1;
     T a[4], qt[9];
@@ -830,7 +863,7 @@ XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &
         for (int k = 0; k < 3; k++) { L.bv[o][k] = (T)0; L.bw[o][k] = (T)0; }
     }
 #pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++) substep<T, Lds, Xchg>(L, qt, lds, arm, x);
+    for (int k = 0; k < xm::HO_N_TICKS; k++) substep<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
     bool all = true;
     T rew = (T)0;
 #pragma unroll

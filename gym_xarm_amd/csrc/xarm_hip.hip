@@ -83,7 +83,11 @@ static unsigned ho_coop_grid(int64_t cap) {
 // kernel the rest; both are launched, the one out of its range exits at once (the count lives on the device)
 static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, const int *count, float *obs_dev, float *ag_dev, float *dg_dev,
                             hipStream_t st) {
-    if (h->cfg.num_obj == 2) { k_ho2_reset<<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev); return; }
+    if (h->cfg.num_obj == 2) {
+        if (h->kp.hcfg.use_stand) k_ho2_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        else k_ho2_reset<xh::HandoverScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        return;
+    }
     const int64_t cap = h->kp.num_envs < (int64_t)h->kp.coop_limit ? h->kp.num_envs : (int64_t)h->kp.coop_limit;
     if (cap > 0) {
         if (h->kp.hcfg.use_stand) k_ho_reset_coop<xh::HandoverStandScene><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
@@ -159,8 +163,8 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     if (stack && cfg->num_obj != 3) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower has num_obj == 3 (xarm_stack_tower.py:19)");
     if (stack && cfg->reward_type > 1) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmStackTower reward_type is 0 (sparse) or 1 (-d)");
     if (handover && cfg->num_obj != 1 && cfg->num_obj != 2) return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover supports num_obj 1 or 2");
-    if (handover && cfg->num_obj == 2 && (cfg->reward_type != 0 || cfg->use_stand))
-        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover with num_obj == 2 takes the sparse reward and no stand (the reference's dense branch raises a broadcast error there, xarm_handover.py:187-188)");
+    if (handover && cfg->num_obj == 2 && cfg->reward_type != 0)
+        return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmHandover with num_obj == 2 takes the sparse reward (the reference's dense branch raises a broadcast error there, xarm_handover.py:187-188)");
     if (!reach && !stack && !handover && cfg->num_obj != 1)
         return fail(nullptr, XARM_E_INVALID, "%s", "xarm_create: XarmPickAndPlace supports num_obj == 1 (with more the reference's own step raises, xarm_pick_and_place.py:289-291)");
     if (handover && cfg->reward_type != 0 && cfg->reward_type != XARM_REWARD_DENSE)
@@ -381,9 +385,12 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         k_st_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                        terminal_obs_dev, h->done_list, cnt, h->class_order, h->class_key);
     }
-    else if (handover && h->cfg.num_obj == 2)
-        k_ho2_step<<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+    else if (handover && h->cfg.num_obj == 2) {
+        if (h->kp.hcfg.use_stand) k_ho2_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                         terminal_obs_dev, h->done_list, cnt);
+        else k_ho2_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                        terminal_obs_dev, h->done_list, cnt);
+    }
     else if (handover && h->fast_pipeline) {
         // as for PickAndPlace below: every env on the pad-free fast lane-pair step, the ones with an active finger-pad row
         // handed off, untouched, to the cooperative rows (lists of at most eject_coop_cap envs) or to k_ho_step (longer)

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(WG) void k_ho2_init(KParams P) {
     h2_store(P, e, arm, L);
 }
 
+template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                  float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restr
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    xh2::lane_step<float, DevLds, DppXchg>(L, arm, act, reward, done, success, lds, DppXchg());
+    xh2::lane_step<float, DevLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg());
     const int64_t e = late_index(e_in);
     h2_store(P, e, arm, L);
     h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restr
     }
 }
 
+template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho2_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                   float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
     __shared__ float smem[xh2::LDS_FLOATS * WG];
@@ -130,13 +132,28 @@ __global__ __launch_bounds__(WG) void k_ho2_reset(KParams P, const int *__restri
     DevLds lds{smem + threadIdx.x};
     xh2::Lane<float> L;
     h2_load(P, e_in, arm, L);
-    xh2::lane_reset<float, DevLds, DppXchg>(P.hcfg, e_in, L, arm, lds, DppXchg());
+    xh2::lane_reset<float, DevLds, DppXchg, Scene>(P.hcfg, e_in, L, arm, lds, DppXchg());
     const int64_t e = late_index(e_in);
     h2_store(P, e, arm, L);
     if (obs_out) h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
 }
 
 // xarm_handover.py:177-183 over n rows of 6: -sum_i [|ag_i - g_i| > thr]
+template __global__ void k_ho2_step<xh::HandoverScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                 int *__restrict__ done_list, int *__restrict__ done_count);
+template __global__ void k_ho2_reset<xh::HandoverScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                  float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
+template __global__ void k_ho2_step<xh::HandoverStandScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                 int *__restrict__ done_list, int *__restrict__ done_count);
+template __global__ void k_ho2_reset<xh::HandoverStandScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                  float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
+
 __global__ void k_ho2_compute_reward(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

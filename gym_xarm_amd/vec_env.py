@@ -353,7 +353,7 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
     Panda-gripper arms, config['num_obj'] = 1 or 2 sticks, two tables with a gap; obs 13 N + 16 = 29 / 42 (:325-329),
     achieved / desired goal 3 N, action 8 (:118), sparse reward -sum_i [d_i > 0.05] (:177-183) or, for one stick, the
     staged dense reward (:184-199); done = success (every stick within 0.05 of its goal, :395-402) or 100 steps (:138 +
-    registry); config['use_stand'] (:391-392, one stick): a static stand under the goal.  num_obj = 2 is the reference's
+    registry); config['use_stand'] (:391-392): a static stand under every goal.  num_obj = 2 is the reference's
     test.py configuration (test.py:9-15): the second stick / goal are rejection-sampled (:357-360, :375-379)."""
 
     ENV_KIND = _native.ENV_HANDOVER
@@ -373,8 +373,6 @@ class XarmHandoverVecEnv(XarmPickAndPlaceVecEnv):
             # not runnable in the reference either: grip_pos_1 (3,) - achieved_goal (6,) is a NumPy broadcast error (:187)
             raise NotImplementedError("XarmHandover reward_type 'dense' with num_obj == 2 raises in the reference itself "
                                       "(xarm_handover.py:187-188: a (3,) grip position minus the (6,) achieved_goal)")
-        if cfg["num_obj"] == 2 and cfg["use_stand"]:
-            raise NotImplementedError("use_stand with num_obj == 2 is not built (test.py:9-15 runs without stands)")
         self.AG_SLICE = slice(0, 3 * cfg["num_obj"])
         return cfg
 

@@ -327,14 +327,14 @@ class OracleReach:
 
 class OracleHandover:
     """Batched CPU XarmHandover-v0 (xarm_handover.py), float64.  num_obj = 1 (BASELINE config 5) or 2 (the reference's
-    test.py configuration; sparse reward, no stand)."""
+    test.py configuration; sparse reward; use_stand: one stand per goal, :391-392)."""
 
     def __init__(self, num_envs, seed=0, env_id_offset=0, same_side_rate=0.5, goal_shape="ground", reward_type="sparse", use_stand=False,
                  num_obj=1):
         self.L = lib()
         assert num_obj in (1, 2)
-        if num_obj == 2 and (reward_type != "sparse" or use_stand):
-            raise ValueError("num_obj = 2: sparse reward without stand only (the reference's dense branch raises, xarm_handover.py:187-188)")
+        if num_obj == 2 and reward_type != "sparse":
+            raise ValueError("num_obj = 2: sparse reward only (the reference's dense branch raises, xarm_handover.py:187-188)")
         self.num_obj = num_obj
         self.state_dim, self.obs_dim, self.goal_dim = (HO_STATE_DIM, HO_OBS_DIM, 3) if num_obj == 1 else (HO2_STATE_DIM, HO2_OBS_DIM, HO2_GOAL_DIM)
         self._fn = {k: getattr(self.L, ("xo_ho_" if num_obj == 1 else "xo_ho2_") + k) for k in ("init", "reset", "step", "compute_reward")}

@@ -1204,6 +1204,39 @@ static void ho_base(const xo_ho_cfg *c, int arm, real *R, real *p) {
     v3_copy(p, c->base_pos[arm]);
 }
 
+/* the static stand under goal g (config['use_stand'], xarm_handover.py:391-392): the candidates of a stick's support
+ * manifold against the stand's top rectangle - the overlap of the footprint of the stick's most downward face with the
+ * rectangle (both axis-aligned), on the face's plane.  Returns 0 (no overlap) or 4; dist[v] = gap to the stand's top. */
+static int ho_stand_points(const xo_ho_cfg *c, const real *Rb, const real *bp, const real *h, const real *g, real pts[4][3], real dist[4]) {
+    real top = g[2] - c->stand_below_goal + c->stand_half[2];
+    int kf = 0;
+    real sgn = 1, bestz = 1e30;
+    for (int k = 0; k < 3; k++)
+        for (int sg = -1; sg <= 1; sg += 2) {
+            real nz = sg * Rb[2 * 3 + k];            /* z component of the face normal sg * axis k */
+            if (nz < bestz) { bestz = nz; kf = k; sgn = sg; }
+        }
+    int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
+    real nf[3] = {sgn * Rb[0 * 3 + kf], sgn * Rb[1 * 3 + kf], sgn * Rb[2 * 3 + kf]}, fc[3];
+    for (int r = 0; r < 3; r++) fc[r] = bp[r] + nf[r] * h[kf];
+    real xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
+    for (int v = 0; v < 4; v++) {
+        real s1 = (v & 1) ? h[k1] : -h[k1], s2 = (v & 2) ? h[k2] : -h[k2];
+        real x = fc[0] + s1 * Rb[0 * 3 + k1] + s2 * Rb[0 * 3 + k2], y = fc[1] + s1 * Rb[1 * 3 + k1] + s2 * Rb[1 * 3 + k2];
+        xlo = x < xlo ? x : xlo; xhi = x > xhi ? x : xhi; ylo = y < ylo ? y : ylo; yhi = y > yhi ? y : yhi;
+    }
+    real ox0 = xlo > g[0] - c->stand_half[0] ? xlo : g[0] - c->stand_half[0], ox1 = xhi < g[0] + c->stand_half[0] ? xhi : g[0] + c->stand_half[0];
+    real oy0 = ylo > g[1] - c->stand_half[1] ? ylo : g[1] - c->stand_half[1], oy1 = yhi < g[1] + c->stand_half[1] ? yhi : g[1] + c->stand_half[1];
+    if (!(ox0 < ox1 && oy0 < oy1)) return 0;
+    for (int v = 0; v < 4; v++) {
+        real x = (v & 1) ? ox1 : ox0, y = (v & 2) ? oy1 : oy0;
+        real z = fc[2] - (nf[0] * (x - fc[0]) + nf[1] * (y - fc[1])) / nf[2];      /* on the face's plane; nf[2] <= -1/sqrt(3) */
+        pts[v][0] = x; pts[v][1] = y; pts[v][2] = z;
+        dist[v] = z - top;
+    }
+    return 4;
+}
+
 static void ho_substep(const xo_model *m, const xo_ho_cfg *c, real *st, const real qt[2][XO_MAXD], real dt) {
     static const real finger_sign[2] = {1.0, -1.0};
     solver_t s;
@@ -1263,36 +1296,15 @@ static void ho_substep(const xo_model *m, const xo_ho_cfg *c, real *st, const re
      * zeroes the stick's roll and yaw every step, :282-297) gives up to four support points on the face's plane with
      * the stand's normal +z; they join the <= 4 point object/support manifold after the corners, no warm start. */
     if (c->use_stand) {
-        const real *g = st + H_GOAL;
-        real top = g[2] - c->stand_below_goal + c->stand_half[2];
-        int kf = 0;
-        real sgn = 1, bestz = 1e30;
-        for (int k = 0; k < 3; k++)
-            for (int sg = -1; sg <= 1; sg += 2) {
-                real nz = sg * s.Rb[2 * 3 + k];            /* z component of the face normal sg * axis k */
-                if (nz < bestz) { bestz = nz; kf = k; sgn = sg; }
-            }
-        int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
-        real nf[3] = {sgn * s.Rb[0 * 3 + kf], sgn * s.Rb[1 * 3 + kf], sgn * s.Rb[2 * 3 + kf]}, fc[3];
-        for (int r = 0; r < 3; r++) fc[r] = bp[r] + nf[r] * h[kf];
-        real xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
-        for (int v = 0; v < 4; v++) {
-            real s1 = (v & 1) ? h[k1] : -h[k1], s2 = (v & 2) ? h[k2] : -h[k2];
-            real x = fc[0] + s1 * s.Rb[0 * 3 + k1] + s2 * s.Rb[0 * 3 + k2], y = fc[1] + s1 * s.Rb[1 * 3 + k1] + s2 * s.Rb[1 * 3 + k2];
-            xlo = x < xlo ? x : xlo; xhi = x > xhi ? x : xhi; ylo = y < ylo ? y : ylo; yhi = y > yhi ? y : yhi;
+        real pts[4][3], dd[4];
+        int np = ho_stand_points(c, s.Rb, bp, h, st + H_GOAL, pts, dd);
+        for (int v = 0; v < np; v++) {
+            real n[3] = {0, 0, 1};
+            int active = dd[v] < m->solver_margin && dd[v] > -(2 * c->stand_half[2] + 0.01) && n_table < 4;
+            if (!active) continue;
+            n_table++;
+            add_contact_arm(&s, 0, -1, pts[v], n, dd[v], dt, m->contact_erp, 0.0, m->mu_object * m->mu_table, 0.0, bp);
         }
-        real ox0 = xlo > g[0] - c->stand_half[0] ? xlo : g[0] - c->stand_half[0], ox1 = xhi < g[0] + c->stand_half[0] ? xhi : g[0] + c->stand_half[0];
-        real oy0 = ylo > g[1] - c->stand_half[1] ? ylo : g[1] - c->stand_half[1], oy1 = yhi < g[1] + c->stand_half[1] ? yhi : g[1] + c->stand_half[1];
-        if (ox0 < ox1 && oy0 < oy1)
-            for (int v = 0; v < 4; v++) {
-                real x = (v & 1) ? ox1 : ox0, y = (v & 2) ? oy1 : oy0;
-                real z = fc[2] - (nf[0] * (x - fc[0]) + nf[1] * (y - fc[1])) / nf[2];      /* on the face's plane; nf[2] <= -1/sqrt(3) */
-                real dist = z - top, p[3] = {x, y, z}, n[3] = {0, 0, 1};
-                int active = dist < m->solver_margin && dist > -(2 * c->stand_half[2] + 0.01) && n_table < 4;
-                if (!active) continue;
-                n_table++;
-                add_contact_arm(&s, 0, -1, p, n, dist, dt, m->contact_erp, 0.0, m->mu_object * m->mu_table, 0.0, bp);
-            }
     }
     /* (M)(L)(G) per arm */
     for (int a = 0; a < 2; a++) {

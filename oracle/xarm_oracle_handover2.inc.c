@@ -95,6 +95,21 @@ static void ho2_substep(const xo_model *m, const xo_ho_cfg *c, real *st, const r
             row_t_n[o * 8 + i] = st_add_contact(&s, -1, -1, o, -1, bp, 0, p, n, dist, dt, m->contact_erp, 0.0,
                                                 m->mu_object * m->mu_table, m->warmstart * st[G_LT + o * 8 + i]);
         }
+        /* (S) config['use_stand'] (:391-392): one stand per goal; the stick's most downward face against the top of either
+         * stand - the one-stick model (ho_stand_points) per (stick, stand) pair, stand 0 before stand 1, after the corners
+         * in the same <= 4 point manifold, no warm start */
+        if (c->use_stand)
+            for (int j = 0; j < H2_NOBJ; j++) {
+                real pts[4][3], dd[4];
+                int np = ho_stand_points(c, Rc[o], bp, h, st + G_GOAL + 3 * j, pts, dd);
+                for (int v = 0; v < np; v++) {
+                    real n[3] = {0, 0, 1};
+                    int active = dd[v] < m->solver_margin && dd[v] > -(2 * c->stand_half[2] + 0.01) && cnt < 4;
+                    if (!active) continue;
+                    cnt++;
+                    st_add_contact(&s, -1, -1, o, -1, bp, 0, pts[v], n, dd[v], dt, m->contact_erp, 0.0, m->mu_object * m->mu_table, 0.0);
+                }
+            }
     }
     /* (BB) stick 0 / stick 1 */
     {

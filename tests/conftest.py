@@ -255,8 +255,9 @@ class HostCore:
         self.L.xh_ho2_init(C.c_int(f32), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs), C.c_int64(E), self._p(st))
         return st
 
-    def ho2_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1):
+    def ho2_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1, use_stand=0):
         E = state.shape[0]
+        self.L.xh_ho_set_use_stand(C.c_int(use_stand))
         st = np.array(state, dtype=np.float64, copy=True)
         a = np.ascontiguousarray(actions, dtype=np.float64)
         obs, ag, dg = np.zeros((E, 42)), np.zeros((E, 6)), np.zeros((E, 6))

@@ -637,8 +637,10 @@ template <typename T> void *h2_thread(void *p) {
         T r = 0; bool d = false, su = false;
         if (J.mode == 0) {
             T a[4]; for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
-            xh2::lane_step<T>(L, J.arm, a, r, d, su, hl, x);
-        } else xh2::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
+            if (J.cfg.use_stand) xh2::lane_step<T, HostLds<T>, PairXchg, xh::HandoverStandScene>(L, J.arm, a, r, d, su, hl, x);
+            else xh2::lane_step<T>(L, J.arm, a, r, d, su, hl, x);
+        } else if (J.cfg.use_stand) xh2::lane_reset<T, HostLds<T>, PairXchg, xh::HandoverStandScene>(J.cfg, e, L, J.arm, hl, x);
+        else xh2::lane_reset<T>(J.cfg, e, L, J.arm, hl, x);
         T o8[8];
         xh2::arm_obs(L, J.arm, o8);
         J.sh->bar.wait();

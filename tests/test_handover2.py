@@ -398,3 +398,94 @@ def test_gpu_reference_test_py_runs_unchanged():
         if i % env._max_episode_steps == 0:
             ob = env.reset()
     env.close()
+
+
+# ------------------------------------------------------------------------------------------- use_stand with two sticks
+def _stand2_scene(oracle, E=6, seed=3):
+    """config['use_stand'] with num_obj = 2 (xarm_handover.py:391-392: one stand per goal): sticks 2 mm above air goals.  Envs
+    0-2: each stick over its own stand; env 3: the sticks swapped (each over the OTHER goal's stand: supported, not a success);
+    env 4: stick 0 3 cm off centre (still supported), stick 1 9 cm off (tips off its stand); env 5: goals on the table"""
+    env = oracle.OracleHandover(E, seed=seed, num_obj=2, goal_shape="any", use_stand=True)
+    env.reset()
+    st = env.get_state()
+    # (clear of the arms' home poses at (-+0.15, 0, 0.15): the grippers would hold the sticks)
+    g0 = np.array([[-0.22, 0.13, 0.15], [-0.15, 0.12, 0.1], [0.2, -0.13, 0.18], [-0.22, 0.13, 0.15], [-0.22, 0.13, 0.15], [-0.25, 0.1, 0.025]])
+    g1 = np.array([[0.2, -0.13, 0.12], [0.18, -0.12, 0.2], [-0.2, 0.14, 0.1], [0.2, -0.13, 0.12], [0.2, -0.13, 0.12], [0.25, -0.1, 0.025]])
+    st[:, GOAL0], st[:, GOAL1] = g0, g1
+    st[:, BP0], st[:, BP1] = g0 + [0, 0, 0.002], g1 + [0, 0, 0.002]
+    st[3, BP0], st[3, BP1] = g1[3] + [0, 0, 0.002], g0[3] + [0, 0, 0.002]
+    st[4, 38] += 0.03
+    st[4, 41] += 0.09
+    st[:, 44:52] = [0, 0, 0, 1, 0, 0, 0, 1]
+    st[:, 52:64] = 0
+    st[:, 70:94] = 0
+    return env, st
+
+
+def test_use_stand_two_sticks_statics_in_the_oracle(oracle):
+    env, st = _stand2_scene(oracle)
+    env.set_state(st)
+    for k in range(12):
+        obs, ag, dg, rew, done, succ = env.step(np.zeros((6, 8)))
+    s = env.get_state()
+    assert np.allclose(s[:3, 40], s[:3, 66], atol=1e-3) and np.allclose(s[:3, 43], s[:3, 69], atol=1e-3) and succ[:3].all() and (rew[:3] == 0).all()
+    assert np.allclose(s[3, 40], s[3, 69], atol=1e-3) and np.allclose(s[3, 43], s[3, 66], atol=1e-3) and not succ[3] and rew[3] == -2   # on each other's stands
+    assert abs(s[4, 40] - s[4, 66]) < 1e-3 and s[4, 43] < s[4, 69] - 0.03 and rew[4] == -1                                              # one supported, one tipping off
+    assert succ[5]                                                                                                                     # goals on the table: stands flush with it
+    off = oracle.OracleHandover(6, seed=3, num_obj=2, goal_shape="any", use_stand=False)
+    off.reset()
+    off.set_state(st)
+    for k in range(12):
+        _, _, _, _, _, succ0 = off.step(np.zeros((6, 8)))
+    s0 = off.get_state()
+    assert np.allclose(s0[:5, 40], 0.025, atol=2e-3) and np.allclose(s0[:5, 43], 0.025, atol=2e-3) and not succ0[:5].any() and succ0[5]
+
+
+def test_use_stand_two_sticks_hostcore_f64_equals_oracle(oracle, hostcore):
+    env, st = _stand2_scene(oracle)
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        a = rng.uniform(-0.3, 0.3, (6, 8))
+        env.set_state(st)
+        env.step(a)
+        nxt = env.get_state()
+        hs, *_ = hostcore.ho2_step(st, a, f32=0, seed=3, gs=0, use_stand=1)
+        np.testing.assert_allclose(hs, nxt, atol=1e-9)
+        h32, *_ = hostcore.ho2_step(st, a, f32=1, seed=3, gs=0, use_stand=1)
+        assert np.median(np.abs(h32 - nxt)[:, :64].max(axis=1)) < 2e-4
+        st = nxt
+    assert (nxt[:, 40] > 0.05).sum() >= 3 and (nxt[:, 43] > 0.05).sum() >= 3     # sticks still up on their stands
+
+
+@pytest.mark.gpu
+def test_gpu_handover2_use_stand(oracle, sharded_handover):
+    """use_stand=True with two sticks through the C ABI: statics on the stands and transition parity against the oracle"""
+    import torch
+    import gym_xarm_amd as gx
+    from oracle import parity
+    ora, st = _stand2_scene(oracle)
+    E = st.shape[0]
+    cfg = {"GUI": False, "num_obj": 2, "same_side_rate": 0.5, "goal_shape": "any", "use_stand": True}
+    env = gx.make("XarmHandover-v0", num_envs=E, seed=3, auto_reset=False, config=cfg)
+    env.set_state(st)
+    for k in range(12):
+        obs, rew, done, info = env.step(torch.zeros(E, 8))
+    s = env.get_state().cpu().numpy()
+    assert np.allclose(s[:3, 40], s[:3, 66], atol=2e-3) and np.allclose(s[:3, 43], s[:3, 69], atol=2e-3) and info["is_success"].cpu().numpy()[:3].all()
+    assert np.allclose(s[3, 40], s[3, 69], atol=2e-3) and s[4, 43] < s[4, 69] - 0.03
+    sh = sharded_handover(oracle, E, 1, seed=3, num_obj=2, goal_shape="any", use_stand=True)
+    rng = np.random.default_rng(1)
+    n_tight = n = 0
+    for k in range(8):
+        a = rng.uniform(-0.4, 0.4, (E, 8))
+        o, nxt = sh.step_from(st, a)
+        sens = sh.sens(st, a, nxt, CONT, [slice(44, 48), slice(48, 52)], k)
+        env.set_state(st)
+        env.step(torch.tensor(a, dtype=torch.float32))
+        dev = env.get_state().cpu().numpy().astype(np.float64)
+        stats = parity.compare(dev[:, CONT], nxt[:, CONT], sens, what="handover2 stand t=%d" % k, frac_tight=0.5, max_exempt=0.5)
+        n_tight += stats["frac_tight"] * E
+        n += E
+        st = nxt
+    assert n_tight >= 0.8 * n
+    env.close()

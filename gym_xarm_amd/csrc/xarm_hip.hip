@@ -597,6 +597,16 @@ int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t 
     *step_coop_limit = h->coop_step_limit;
     return XARM_OK;
 }
+int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, void *stream) {
+    if (!h || !finished || !handed_off) return XARM_E_INVALID;
+    DEVGUARD(h);
+    int c[2] = {0, 0};
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(h, hipMemcpy(c, h->counters, sizeof c, hipMemcpyDeviceToHost));
+    *finished = c[0];
+    *handed_off = h->fast_pipeline ? c[1] : 0;
+    return XARM_OK;
+}
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
                        int32_t *solver_iterations) {
     if (!h || !fast_pipeline || !reset_overlap || !eject_coop_cap || !solver_iterations) return XARM_E_INVALID;

@@ -288,6 +288,12 @@ class XarmPickAndPlaceVecEnv:
         _native.check(self._L, self._h, self._L.xarm_pipeline_info(self._h, *[C.byref(x) for x in v]), "xarm_pipeline_info")
         return dict(fast_pipeline=bool(v[0].value), reset_overlap=bool(v[1].value), eject_coop_cap=v[2].value, solver_iterations=v[3].value)
 
+    def debug_counts(self):
+        """(episodes that ended in the step kernels, envs handed off by the fast kernel) of the last step() call (development hook)"""
+        v = [C.c_int32(0) for _ in range(2)]
+        _native.check(self._L, self._h, self._L.xarm_debug_counts(self._h, *[C.byref(x) for x in v], self._stream()), "xarm_debug_counts")
+        return tuple(x.value for x in v)
+
     def library(self):
         """(xarm_version(), path of the loaded libxarm_hip.so)"""
         return self._L.xarm_version().decode(), _native.loaded_path()

@@ -180,6 +180,10 @@ int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t 
  *                    xarm_version() says "TIMING VARIANT") */
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
                        int32_t *solver_iterations);
+/* development / test hook: the device-side counters of the LAST xarm_step call, after synchronising `stream` - episodes that
+ * ended in the step kernels (a pipelined PickAndPlace call counts the ones that ended in the hand-off apart: not included) and
+ * envs handed off by the fast kernel to the cooperative one (0 for a handle without the pipeline) */
+int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, void *stream);
 
 /* StackTower: the row-set class each env's last substep fell into, uint8 [E] (bits 0-2 cube pairs (0,1) (0,2) (1,2) in
  * contact, bit 3 / 4 a finger pad of arm 0 / 1 active).  The step

@@ -13,6 +13,11 @@ UNITS = ["xarm_hip.hip", "xarm_k_pnp.hip", "xarm_k_pnp_coop.hip", "xarm_k_reach.
 HEADERS = ["xarm_dev.h", "xarm_core.h", "xarm7_pd_model.h", "xarm_reach_core.h", "xarm7_reach_model.h", "xarm_handover_core.h", "xarm_handover2_core.h",
            "xarm_stack_core.h", "xarm_coop_core.h", "xarm_reach_coop_core.h", "xarm_handover_coop_core.h"]
 SOURCES = UNITS + HEADERS
+# per-unit extra flags.  Tried and not shipped: "-ffp-contract=on" for xarm_k_pnp.hip / xarm_k_handover.hip (fused multiply-adds
+# only where the source writes them, so that k_step_fast / k_ho_step_fast compute the BITS of k_step / k_ho_step on every env
+# they accept, as the host build does) - it holds, and costs 2.6 % of the headline (k_step_fast + hand-off 1.35 -> 1.43 ms,
+# k_step 2.02 -> 2.22 ms) and 6 % of Handover: the default `fast` contraction stays, the families agree to float32 rounding.
+UNIT_FLAGS = {}
 # -fno-slp-vectorize: LLVM's SLP pass pairs the scalar fp32 ops of the unrolled solver into v_pk_* instructions,
 # which need even-aligned register pairs; in this 400-live-value kernel that costs ~30 % extra v_mov and pushes
 # 1.3 KB/lane into scratch.  Without it the step kernel needs 28 B/lane of scratch and 18 % fewer instructions.
@@ -62,7 +67,7 @@ def build(force=False, verbose=True, extra_flags=(), lib=LIB, jobs=None):
     for u in UNITS:
         o = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
         objs.append(o)
-        jobs_l.append(([hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, u)], verbose))
+        jobs_l.append(([hipcc] + HIPCC_FLAGS + UNIT_FLAGS.get(u, []) + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, u)], verbose))
     with ThreadPoolExecutor(jobs or min(len(UNITS), os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, jobs_l))
     _compile(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, verbose))

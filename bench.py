@@ -420,6 +420,9 @@ def main():
         reset_entry = {"name": reset_kernel, "avg_ms": reset_ms, "share": reset_ms / call_ms, "resets_per_call": resets_per_call,
                        "algorithmic_bytes_per_launch": reset_algo, "traffic": reset_traffic}
         reset_entry["avg_ms_is"] = "reset kernels, on the caller's stream after the step kernel(s)"
+        if pipe["reset_overlap"] and reset_traffic:
+            reset_entry["launches_per_call"] = 2          # `traffic` is the PMC average of ONE launch that did work
+            reset_entry["traffic_per_call"] = 2 * reset_traffic
         if pipe["reset_overlap"]:
             # the first reset launch runs on the handle's side stream beside the hand-off: the bracket holds what is LEFT of the resets
             # after the hand-off, so step + reset no longer partitions the kernels' own time and no rate is derived from it

@@ -425,8 +425,14 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 
     // ---------------- (F) finger pad spheres, each against its nearest cube
     constexpr int NP = xk::NP;
+    static_assert(xm::NPAD == 2, "the finger block of the sweep fuses exactly two pad points per finger");
     PadPoint<T> pp[NP];
     int pc[NP];
+    T K21[2][9];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) K21[k][e] = (T)0;
     bool pad_any = false;
     const T pad_denom = dt * (T)xm::FINGER_CONTACT_STIFFNESS + (T)(xm::FINGER_CONTACT_DAMPING + xm::OBJECT_CONTACT_DAMPING);
     const T pad_cfm = ((T)1 / pad_denom) * idt, pad_erp = dt * (T)xm::FINGER_CONTACT_STIFFNESS / pad_denom;
@@ -546,6 +552,35 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
                 for (int k = 0; k < 6; k++) s += lds[LDS_T + r * 6 + k] * wtot[k];
                 dq[r] += s;
+            }
+            // arm-side coupling of the two pad points of each finger: velocity of the finger at its second point per unit
+            // impulse at its first one (3x3, row-major) - lets both points be swept before ONE operational-space update
+            // (as xk::substep; the cube side is applied to the cube velocities point by point)
+#pragma unroll
+            for (int fk = 0; fk < 2; fk++) {
+                const PadPoint<T> &P1 = pp[2 * fk], &P2 = pp[2 * fk + 1];
+                if (!XARM_ANY(P1.invd[0] != (T)0 && P2.invd[0] != (T)0)) continue;
+                const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const V3<T> ej = mk<T>(e == 0 ? (T)1 : (T)0, e == 1 ? (T)1 : (T)0, e == 2 ? (T)1 : (T)0);
+                    const V3<T> mo = cross(P1.p, ej);
+                    const T W[6] = {mo.x, mo.y, mo.z, ej.x, ej.y, ej.z};
+                    const T wf = xk::comp(af, e);
+                    T Y[6];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
+#pragma unroll
+                        for (int b = 0; b < 6; b++) s += lds[LDS_AHH + symi(a, b)] * W[b];
+                        Y[a] = s;
+                    }
+                    T yf = Minv[tri(7 + fk, 7 + fk)] * wf;
+#pragma unroll
+                    for (int b = 0; b < 6; b++) yf += lds[LDS_T + (7 + fk) * 6 + b] * W[b];
+                    const V3<T> va = mk<T>(Y[3], Y[4], Y[5]) + cross(mk<T>(Y[0], Y[1], Y[2]), P2.p) + af * yf;
+                    K21[fk][0 * 3 + e] = va.x; K21[fk][1 * 3 + e] = va.y; K21[fk][2 * 3 + e] = va.z;
+                }
             }
         }
         // the cubes also receive the warm-start impulses of the other arm's pads; afterwards both lanes must hold
@@ -735,39 +770,58 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
                 for (int k = 0; k < 8; k++) wtot[k] = (T)0;
 #pragma unroll
-                for (int idx = 0; idx < NP; idx++) {
-                    PadPoint<T> &P = pp[idx];
-                    if (!XARM_ANY(P.invd[0] != (T)0 && mine)) continue;
-                    const T e0 = mine ? P.invd[0] : (T)0, e1 = mine ? P.invd[1] : (T)0, e2 = mine ? P.invd[2] : (T)0;
-                    const int fk = idx / xm::NPAD, co = pc[idx];
+                for (int fk = 0; fk < 2; fk++) {
+                    if (!XARM_ANY((pp[2 * fk].invd[0] != (T)0 || pp[2 * fk + 1].invd[0] != (T)0) && mine)) continue;
                     const V3<T> af = hc1 * (fk == 0 ? (T)1 : (T)-1);
-                    const V3<T> r = P.p - sel3v(co, cb[0], cb[1], cb[2]);
-                    const V3<T> vc = sel3v(co, vb[0], vb[1], vb[2]), wc = sel3v(co, wb[0], wb[1], wb[2]);
-                    const V3<T> t2 = cross(P.n, P.t1);
-                    V3<T> u = mk<T>(y[3], y[4], y[5]) + cross(mk<T>(y[0], y[1], y[2]), P.p) + af * yf[fk] - vc - cross(wc, r);
-                    T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
-                    T nl = P.lam[0] + dl;
-                    nl = xk::smax0(nl);
-                    dl = nl - P.lam[0];
-                    P.lam[0] = nl;
-                    V3<T> fi = P.n * dl;
-                    u = u + P.Kn * dl;
-                    const T lim = mu_p * P.lam[0];
-                    dl = -dot(P.t1, u) * e1;
-                    nl = xk::sclamp(P.lam[1] + dl, -lim, lim);
-                    dl = nl - P.lam[1];
-                    P.lam[1] = nl;
-                    fi = fi + P.t1 * dl;
-                    u = u + P.Kt1 * dl;
-                    dl = -dot(t2, u) * e2;
-                    nl = xk::sclamp(P.lam[2] + dl, -lim, lim);
-                    dl = nl - P.lam[2];
-                    P.lam[2] = nl;
-                    fi = fi + t2 * dl;
-                    // apply the block impulse: +fi on finger fk at p, -fi on the cube
-                    const V3<T> mo = cross(P.p, fi);
-                    const T W[6] = {mo.x, mo.y, mo.z, fi.x, fi.y, fi.z};
-                    const T wf = dot(af, fi);
+                    const V3<T> yw = mk<T>(y[0], y[1], y[2]);
+                    const V3<T> base = mk<T>(y[3], y[4], y[5]) + af * yf[fk];
+                    V3<T> fsum = mk<T>(0, 0, 0), msum = mk<T>(0, 0, 0), f1 = mk<T>(0, 0, 0);   // sum f, sum p x f, the first point's impulse
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        PadPoint<T> &P = pp[2 * fk + j];
+                        const int co = pc[2 * fk + j];
+                        const T e0 = mine ? P.invd[0] : (T)0, e1 = mine ? P.invd[1] : (T)0, e2 = mine ? P.invd[2] : (T)0;
+                        const V3<T> r = P.p - sel3v(co, cb[0], cb[1], cb[2]);
+                        const V3<T> vc = sel3v(co, vb[0], vb[1], vb[2]), wc = sel3v(co, wb[0], wb[1], wb[2]);
+                        const V3<T> t2 = cross(P.n, P.t1);
+                        V3<T> u = base + cross(yw, P.p) - vc - cross(wc, r);
+                        if (j == 1) // effect on the finger of the impulse just applied at its first point (the cube side went into vb / wb)
+                            u = u + mk<T>(K21[fk][0] * f1.x + K21[fk][1] * f1.y + K21[fk][2] * f1.z,
+                                          K21[fk][3] * f1.x + K21[fk][4] * f1.y + K21[fk][5] * f1.z,
+                                          K21[fk][6] * f1.x + K21[fk][7] * f1.y + K21[fk][8] * f1.z);
+                        T dl = (P.vt - pad_cfm * P.lam[0] - dot(P.n, u)) * e0;
+                        T nl = P.lam[0] + dl;
+                        nl = xk::smax0(nl);
+                        dl = nl - P.lam[0];
+                        P.lam[0] = nl;
+                        V3<T> fi = P.n * dl;
+                        u = u + P.Kn * dl;
+                        const T lim = mu_p * P.lam[0];
+                        dl = -dot(P.t1, u) * e1;
+                        nl = xk::sclamp(P.lam[1] + dl, -lim, lim);
+                        dl = nl - P.lam[1];
+                        P.lam[1] = nl;
+                        fi = fi + P.t1 * dl;
+                        u = u + P.Kt1 * dl;
+                        dl = -dot(t2, u) * e2;
+                        nl = xk::sclamp(P.lam[2] + dl, -lim, lim);
+                        dl = nl - P.lam[2];
+                        P.lam[2] = nl;
+                        fi = fi + t2 * dl;
+                        if (j == 0) f1 = fi;
+                        fsum = fsum + fi;
+                        msum = msum + cross(P.p, fi);
+                        // -fi on the cube, at once: the finger's second point may press on the same cube
+                        const V3<T> dv = fi * imb, dw = cross(r, fi) * ii;
+#pragma unroll
+                        for (int o = 0; o < NOBJ; o++) {
+                            vb[o] = co == o ? vb[o] - dv : vb[o];
+                            wb[o] = co == o ? wb[o] - dw : wb[o];
+                        }
+                    }
+                    // ONE operational-space update for the finger: +fsum on finger fk, moment msum about the world origin
+                    const T W[6] = {msum.x, msum.y, msum.z, fsum.x, fsum.y, fsum.z};
+                    const T wf = dot(af, fsum);
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
                         T s = lds[LDS_T + (7 + fk) * 6 + a] * wf;
@@ -785,12 +839,6 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
 #pragma unroll
                     for (int b = 0; b < 6; b++) wtot[b] += W[b];
                     wtot[6 + fk] += wf;
-                    const V3<T> dv = fi * imb, dw = cross(r, fi) * ii;
-#pragma unroll
-                    for (int o = 0; o < NOBJ; o++) {
-                        vb[o] = co == o ? vb[o] - dv : vb[o];
-                        wb[o] = co == o ? wb[o] - dw : wb[o];
-                    }
                 }
                 XARM_DQ_AXPY(7, wtot[6]);
                 XARM_DQ_AXPY(8, wtot[7]);

@@ -1,4 +1,4 @@
-"""Development aid: which envs of a batch keep the bits of the plain step kernel under the fast pipeline (PickAndPlace, Handover), step by step,\nnext to the hand-off count - all but the handed-off ones in a build with -ffp-contract=on, a minority in the default build (gym_xarm_amd/build.py)."""
+"""Development aid: which envs of a batch keep the bits of the plain step kernel under the fast pipeline (PickAndPlace, Handover), step by step, next to the hand-off count - all but the handed-off ones in a build with -ffp-contract=on, a minority in the default build (gym_xarm_amd/build.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gym_xarm_amd as gx

@@ -8,8 +8,13 @@ import json
 import os
 import sys
 
-STEP_KERNEL = {"pnp": "k_step_fast", "reach": "k_reach_step", "handover": "k_ho_step", "stack": "k_st_step"}
-RESET_KERNEL = {"pnp": "k_reset_coop", "reach": "k_reach_reset", "handover": "k_ho_reset", "stack": "k_st_reset"}
+# candidates per role, the first one present in the summary with counters wins (the fast pipeline's first kernel, the plain
+# kernel when the pipeline is off, the cooperative family at small batch sizes)
+STEP_KERNEL = {"pnp": ["k_step_fast", "k_step", "k_step_coop"], "reach": ["k_reach_step", "k_reach_step_coop"],
+               "handover": ["k_ho_step_fast", "k_ho_step"], "stack": ["k_st_step"], "handover2": ["k_ho2_step"]}
+RESET_KERNEL = {"pnp": ["k_reset_coop", "k_reset"], "reach": ["k_reach_reset", "k_reach_reset_coop"],
+                "handover": ["k_ho_reset_coop", "k_ho_reset"], "stack": ["k_st_reset"], "handover2": ["k_ho2_reset"]}
+HANDOFF_KERNEL = {"pnp": ["k_step_coop_list"], "handover": ["k_ho_step_coop_list"]}
 
 
 def main():
@@ -20,14 +25,15 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = os.path.join(root, "profiles", "pmc_traffic.json")
     t = json.load(open(out)) if os.path.exists(out) else (json.load(open(base)) if os.path.exists(base) else {})
-    for role, names in (("step", STEP_KERNEL), ("reset", RESET_KERNEL)):
-        k = names[wl]
-        if k == "k_step_fast" and k not in d:    # plain kernel (pipeline off) or the cooperative family
-            k = "k_step"
-        if k not in d and k + "_coop" in d:      # the cooperative family served this batch size (pnp, reach)
-            k = k + "_coop"
-        if k not in d or "FETCH_SIZE" not in d[k] or "WRITE_SIZE" not in d[k]:
+    def usable(k):
+        return k in d and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k] and d[k].get("SQ_WAVE_CYCLES", {"avg_per_launch": 1})["avg_per_launch"] > 0
+    for role, names in (("step", STEP_KERNEL), ("reset", RESET_KERNEL), ("handoff", HANDOFF_KERNEL)):
+        ks = [k for k in names.get(wl, []) if usable(k)]
+        # a kernel launched beside its twin and out of its count range does nothing: take the candidate that moved the most bytes
+        ks.sort(key=lambda k: -(2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"]))
+        if not ks:
             continue
+        k = ks[0]
         hbm = (2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024
         t["%s_hbm_bytes_per_launch_%d" % (k, E)] = hbm
         if "SQ_INSTS_VALU" in d[k]:

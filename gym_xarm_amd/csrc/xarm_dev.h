@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
                                                           const int *__restrict__ list, const int *__restrict__ count);
-template <typename Scene>
+template <typename Scene, bool FORCE_COUPLED>
 __global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                       float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
 __global__ __launch_bounds__(WG) void k_ho2_init(KParams P);

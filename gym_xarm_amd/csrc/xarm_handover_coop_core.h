@@ -87,7 +87,8 @@ XARM_HD void solve(const Grp &G, const Setup<T> &S, const bool (&padw)[NP], Lds 
 // of xc::apply_warm_start / xc::sweep_all, and a cross term whose impulse is zero changes nothing: for an environment
 // with one touching arm this is bit for bit the decoupled form.
 template <typename T, bool LA, typename X>
-XARM_HD void sweep_coupled(const Grp &G, const X &x, Sweep<T> &W, LV<T> (&XT)[NF], LV<T> (&XF)[NF], T mu_t, T mu_p, const bool (&padw)[NP]) {
+XARM_HD void sweep_coupled(const Grp &G, const X &x, Sweep<T> &W, LV<T> (&XT)[NF], LV<T> (&XF)[NF], T mu_t, T mu_p, const bool (&padw)[NP],
+                           const bool (&padk)[2][NP]) {
     const bool arm0 = x.arm == 0;
     LV2<T> lam01 = lv2_make(W.lam[0], W.lam[1]);
     const LV2<T> invd01 = lv2_make(W.invd[0], W.invd[1]), zero2 = lv2_make(lv_fill((T)0), lv_fill((T)0));
@@ -113,23 +114,20 @@ XARM_HD void sweep_coupled(const Grp &G, const X &x, Sweep<T> &W, LV<T> (&XT)[NF
 #pragma unroll
         for (int i = 0; i < 7; i++) W.nA2[C2_L + i] = lv_mul(W.nA2[C2_L + i], W.invd[2]);
     }
-    // phase columns: in phase k (the pad rows of arm k) a row uses its own columns when it is arm k, the cross columns
-    // (support rows and pad rows against the other arm's pad rows, through the object) otherwise
-    LV2<T> P01[2][NF];
-    LV<T> P2[2][NF], P3[2][NF];
+    // own pad columns as in xc::sweep_all (scaled by the receiving row's 1 / d, a row's own entry zeroed); the cross columns -
+    // support rows and pad rows against the OTHER arm's pad rows, through the object - likewise.  No per-phase copies: in
+    // phase k a row of arm k uses its own columns, the other row the cross columns, chosen per row step (selects on the
+    // column instead of 72 more registers of per-phase copies, which pushed ~110 B/lane more of the substep's state into
+    // scratch - also on the decoupled path every other environment takes)
+    LV2<T> AF01[NF];
 #define XH_COLF(r)                                                                                           \
     if (padw[(r) / 3]) {                                                                                     \
-        const LV2<T> own01 = lv2_mul(lv2_make(W.nA0[C0_F + r], W.nA1[C1_F + r]), invd01);                    \
-        const LV2<T> crs01 = lv2_mul(lv2_make(XT[r], lv_fill((T)0)), invd01);                                \
-        LV<T> own2 = lv_mul(W.nA2[C2_F + r], W.invd[2]);                                                     \
-        lv_commit<r>(G, own2, lv_fill((T)0));                                                                \
-        const LV<T> crs2 = lv_mul(XF[r], W.invd[2]);                                                         \
-        P01[0][r] = lv2_sel(arm0, own01, crs01); P01[1][r] = lv2_sel(arm0, crs01, own01);                    \
-        P2[0][r] = lv_sel(arm0, own2, crs2); P2[1][r] = lv_sel(arm0, crs2, own2);                            \
-        if (LA) {                                                                                            \
-            const LV<T> own3 = lv_mul(W.nA3[C1_F + r], W.invd[3]);                                           \
-            P3[0][r] = lv_sel(arm0, own3, lv_fill((T)0)); P3[1][r] = lv_sel(arm0, lv_fill((T)0), own3);      \
-        }                                                                                                    \
+        AF01[r] = lv2_mul(lv2_make(W.nA0[C0_F + r], W.nA1[C1_F + r]), invd01);                               \
+        W.nA2[C2_F + r] = lv_mul(W.nA2[C2_F + r], W.invd[2]);                                                \
+        lv_commit<r>(G, W.nA2[C2_F + r], lv_fill((T)0));                                                     \
+        if (LA) W.nA3[C1_F + r] = lv_mul(W.nA3[C1_F + r], W.invd[3]);                                        \
+        XT[r] = lv_mul(XT[r], W.invd[0]);                                                                    \
+        XF[r] = lv_mul(XF[r], W.invd[2]);                                                                    \
     }
     XH_COLF(0) XH_COLF(1) XH_COLF(2) XH_COLF(3) XH_COLF(4) XH_COLF(5) XH_COLF(6) XH_COLF(7) XH_COLF(8) XH_COLF(9) XH_COLF(10) XH_COLF(11)
 #undef XH_COLF
@@ -186,15 +184,17 @@ XARM_HD void sweep_coupled(const Grp &G, const X &x, Sweep<T> &W, LV<T> (&XT)[NF
                 nl = lv_med3(c2, lv_neg(flim), flim);                                                        \
             }                                                                                                \
             const LV<T> dl = lv_sub(nl, W.lam[2]);                                                           \
-            lv_commit_if<3 * p + a>(G, arm0 == ((k) == 0), W.lam[2], nl);                                    \
+            const bool mine = arm0 == ((k) == 0);                                                            \
+            lv_commit_if<3 * p + a>(G, mine, W.lam[2], nl);                                                  \
             LV<T> b0, b1;                                                                                    \
             x.both(lv_bcast<3 * p + a>(dl), b0, b1);                                                         \
-            const LV<T> b = (k) == 0 ? b0 : b1;                                                              \
-            c01 = lv2_fma(P01[k][3 * p + a], lv2_make(b, b), c01);                                           \
-            c2 = lv_fma(P2[k][3 * p + a], b, c2);                                                            \
-            if (LA) c3 = lv_fma(P3[k][3 * p + a], b, c3);                                                    \
+            const LV<T> b = (k) == 0 ? b0 : b1, zero = lv_fill((T)0);                                        \
+            const LV2<T> col01 = lv2_sel(mine, AF01[3 * p + a], lv2_make(XT[3 * p + a], zero));              \
+            c01 = lv2_fma(col01, lv2_make(b, b), c01);                                                       \
+            c2 = lv_fma(lv_sel(mine, W.nA2[C2_F + 3 * p + a], XF[3 * p + a]), b, c2);                        \
+            if (LA) c3 = lv_fma(lv_sel(mine, W.nA3[C1_F + 3 * p + a], zero), b, c3);                         \
         }
-#define XH_F_PAD(k, p) if (padw[p]) { XH_F_ROW(k, p, 0) XH_F_ROW(k, p, 1) XH_F_ROW(k, p, 2) }
+#define XH_F_PAD(k, p) if (padk[k][p]) { XH_F_ROW(k, p, 0) XH_F_ROW(k, p, 1) XH_F_ROW(k, p, 2) }   /* pad p of arm k is live somewhere in the wavefront */
         XH_PAIR(0) XH_PAIR(1) XH_PAIR(2) XH_PAIR(3) XH_PAIR(4) XH_PAIR(5) XH_PAIR(6) XH_PAIR(7) XH_PAIR(8)
         if (LA) { XH_L_ROW(0) XH_L_ROW(1) XH_L_ROW(2) XH_L_ROW(3) XH_L_ROW(4) XH_L_ROW(5) XH_L_ROW(6) }
         XH_PAIR(9) XH_PAIR(10) XH_PAIR(11) XH_PAIR(12) XH_PAIR(13)
@@ -210,7 +210,7 @@ XARM_HD void sweep_coupled(const Grp &G, const X &x, Sweep<T> &W, LV<T> (&XT)[NF
 }
 
 template <typename T, typename Lds, bool LA, typename X, typename Scene>
-XARM_HD void solve_coupled(const Grp &G, const X &x, const Setup<T> &S, const bool (&padw)[NP], Lds lds, Sweep<T> &W, LV<T> (&J)[R_G],
+XARM_HD void solve_coupled(const Grp &G, const X &x, const Setup<T> &S, const bool (&padw)[NP], const bool (&padk)[2][NP], Lds lds, Sweep<T> &W, LV<T> (&J)[R_G],
                            T (&tauJ)[9], T (&pT)[6], T (&pF)[6]) {
     const bool arm0 = x.arm == 0;
     LV<T> cfm = lv_fill((T)0);
@@ -254,7 +254,7 @@ XARM_HD void solve_coupled(const Grp &G, const X &x, const Setup<T> &S, const bo
         XH_WS_T(0) XH_WS_T(1) XH_WS_T(2) XH_WS_T(3)
 #undef XH_WS_T
 #define XH_WS_F(k, p)                                                                                        \
-        if (padw[p]) {                                                                                       \
+        if (padk[k][p]) {                                                                                    \
             const bool mine = arm0 == ((k) == 0);                                                            \
             const LV<T> b = lv_sel(mine, lv_bcast<3 * p>(W.lam[2]), lv_bcast<3 * p>(olam));                  \
             W.g[0] = lv_fma(lv_sel(mine, W.nA0[C0_F + 3 * p], XT[3 * p]), b, W.g[0]);                       \
@@ -267,7 +267,7 @@ XARM_HD void solve_coupled(const Grp &G, const X &x, const Setup<T> &S, const bo
 #undef XH_WS_F
     }
     const T mu_t = (T)(xm::MU_OBJECT * xm::MU_TABLE);
-    sweep_coupled<T, LA, X>(G, x, W, XT, XF, mu_t, S.mu_p, padw);
+    sweep_coupled<T, LA, X>(G, x, W, XT, XF, mu_t, S.mu_p, padw, padk);
     reduce<T, true, LA>(W, J, tauJ, pT, pF);
 }
 
@@ -293,15 +293,26 @@ XARM_HD void substep(const Grp &G, const X &x, const ArmLane<T> &C, EnvState<T> 
     }
     const int mo = (int)(arm0 ? m1 : m0);
     const bool p0 = ((int)m0 & 16) != 0, p1 = ((int)m1 & 16) != 0;
+#ifdef XHC_NO_COUPLED      // timing probe only (wrong for an env with pad rows on both arms): what the coupled path costs the others
+    const bool both = false;
+#else
     const bool both = FORCE_COUPLED || XARM_ANY_X(p0 && p1);
+#endif
     const bool pad = XARM_ANY_X(S.pad_any), la = XARM_ANY_X(S.la_any);
-    bool padw[NP];
+    // padw[p]: pad p of EITHER arm has a live row somewhere in the wavefront (columns are built for it); padk[k][p]: pad p of
+    // arm k has (the rows the coupled sweep and warm start visit in phase k - a skipped row carries exactly zero impulse)
+    bool padw[NP], padk[2][NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) padw[p] = FORCE_COUPLED || XARM_ANY_X(S.pact[p] || (both && (mo >> p & 1)));
+    for (int p = 0; p < NP; p++) {
+        padw[p] = FORCE_COUPLED || XARM_ANY_X(S.pact[p] || (both && (mo >> p & 1)));
+        const bool other = (mo >> p & 1) != 0;
+        padk[0][p] = FORCE_COUPLED || XARM_ANY_X(arm0 ? S.pact[p] : other);
+        padk[1][p] = FORCE_COUPLED || XARM_ANY_X(arm0 ? other : S.pact[p]);
+    }
     T tauJ[9], pT[6], pF[6], oF[6];
     if (both) {
-        if (la) solve_coupled<T, Lds, true, X, Scene>(G, x, S, padw, lds, W, J, tauJ, pT, pF);
-        else solve_coupled<T, Lds, false, X, Scene>(G, x, S, padw, lds, W, J, tauJ, pT, pF);
+        if (la) solve_coupled<T, Lds, true, X, Scene>(G, x, S, padw, padk, lds, W, J, tauJ, pT, pF);
+        else solve_coupled<T, Lds, false, X, Scene>(G, x, S, padw, padk, lds, W, J, tauJ, pT, pF);
 #pragma unroll
         for (int d = 0; d < 6; d++) oF[d] = x.partner(pF[d]);
     } else {

@@ -90,8 +90,9 @@ static void launch_ho_reset(xarm_handle *h, unsigned grid2, const int *list, con
     }
     const int64_t cap = h->kp.num_envs < (int64_t)h->kp.coop_limit ? h->kp.num_envs : (int64_t)h->kp.coop_limit;
     if (cap > 0) {
-        if (h->kp.hcfg.use_stand) k_ho_reset_coop<xh::HandoverStandScene><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
-        else k_ho_reset_coop<xh::HandoverScene><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        if (h->kp.hcfg.use_stand) k_ho_reset_coop<xh::HandoverStandScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        else if (h->ho_force_coupled) k_ho_reset_coop<xh::HandoverScene, true><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
+        else k_ho_reset_coop<xh::HandoverScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);
     }
     if (h->kp.num_envs > cap) {
         if (h->kp.hcfg.use_stand) k_ho_reset<xh::HandoverStandScene><<<dim3(grid2), dim3(WG), 0, st>>>(h->kp, list, count, obs_dev, ag_dev, dg_dev);

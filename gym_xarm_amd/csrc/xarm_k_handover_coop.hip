@@ -11,8 +11,15 @@ struct SwapXchg {
     int arm;
     __device__ __forceinline__ void pair(float v, float &v0, float &v1) const {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v0 = __uint_as_float(r[0]);   // lanes 0-31 (arm 0) everywhere
-        v1 = __uint_as_float(r[1]);   // lanes 32-63 (arm 1) everywhere
+        unsigned r0 = r[0], r1 = r[1];
+        // HAZARD (gfx950, hipcc 7.2): a VALU instruction that reads a register v_permlane32_swap_b32 has just written gets
+        // STALE data when it issues right behind the swap - the compiler pads the other direction (VALU write -> swap read,
+        // s_nop 1) and nothing here.  Found as run-to-run differences of the cooperative reset (a v_fmac reading the swapped
+        // impulse one instruction after the swap; tools/ho_reset_probe.py: 281 of 3 277 envs wrong without the pad, 0 with it).
+        // The asm ties both results, so every consumer sits behind the two wait states.
+        asm volatile("s_nop 1" : "+v"(r0), "+v"(r1));
+        v0 = __uint_as_float(r0);   // lanes 0-31 (arm 0) everywhere
+        v1 = __uint_as_float(r1);   // lanes 32-63 (arm 1) everywhere
     }
     __device__ __forceinline__ float from0(float v) const { float a, b; pair(v, a, b); return a; }
     __device__ __forceinline__ float from1(float v) const { float a, b; pair(v, a, b); return b; }
@@ -89,7 +96,7 @@ template __global__ void k_ho_step_coop_list<xh::HandoverStandScene, false>(KPar
 
 // XarmHandover.reset on the cooperative rows for the envs list[0 .. *count) (null: all), counts up to P.coop_limit (more:
 // k_ho_reset, launched beside this kernel): six ticks of latency for the handful of envs that finish in a step
-template <typename Scene>
+template <typename Scene, bool FORCE_COUPLED>
 __global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                       float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
     __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__re
         const int64_t e_in = list ? (int64_t)list[i] : i;
         xh::Lane<float> L;
         ho_load(P, e_in, x.arm, L);
-        xhc::env_reset<float, DevLds, SwapXchg, Scene>(G, x, P.hcfg, e_in, L, lds);
+        xhc::env_reset<float, DevLds, SwapXchg, Scene, FORCE_COUPLED>(G, x, P.hcfg, e_in, L, lds);
         if (live && G.l == 0) {
             const int64_t e = late_index(e_in);
             ho_store(P, e, x.arm, L);
@@ -116,9 +123,11 @@ __global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__re
     }
 }
 
-template __global__ void k_ho_reset_coop<xh::HandoverScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+template __global__ void k_ho_reset_coop<xh::HandoverScene, false>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                       float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
-template __global__ void k_ho_reset_coop<xh::HandoverStandScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+template __global__ void k_ho_reset_coop<xh::HandoverScene, true>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
+                                                      float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
+template __global__ void k_ho_reset_coop<xh::HandoverStandScene, false>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                       float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
 
 } // namespace xd

@@ -29,11 +29,11 @@ def main():
         return k in d and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k] and d[k].get("SQ_WAVE_CYCLES", {"avg_per_launch": 1})["avg_per_launch"] > 0
     for role, names in (("step", STEP_KERNEL), ("reset", RESET_KERNEL), ("handoff", HANDOFF_KERNEL)):
         ks = [k for k in names.get(wl, []) if usable(k)]
-        # a kernel launched beside its twin and out of its count range does nothing: take the candidate that moved the most bytes
-        ks.sort(key=lambda k: -(2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"]))
         if not ks:
             continue
-        k = ks[0]
+        # a kernel launched beside its twin and out of its count range does nothing: the first candidate that moved a real share
+        nbytes = {k: 2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"] for k in ks}
+        k = [k for k in ks if nbytes[k] > 0.01 * max(nbytes.values())][0]
         hbm = (2 * d[k]["FETCH_SIZE"]["avg_per_launch"] + d[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024
         t["%s_hbm_bytes_per_launch_%d" % (k, E)] = hbm
         if "SQ_INSTS_VALU" in d[k]:

@@ -215,6 +215,13 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     }
     const bool handover2 = handover && cfg->num_obj == 2;
     const bool handover1 = handover && !handover2;
+    // Handover (one stick): small batches step on the cooperative rows altogether - 2 048 envs are one round of 1 024 wavefronts
+    // and one kernel of ~0.6 ms, where the fast lane-pair kernel (0.72 ms whatever the batch, a latency) plus the hand-off take 1.4
+    if (handover1 && cfg->step_coop_limit >= 0) {
+        h->coop_step_limit = cfg->step_coop_limit > 0 ? cfg->step_coop_limit : XARM_HO_STEP_COOP_LIMIT_DEFAULT;
+        const char *ev = getenv("XARM_STEP_COOP_LIMIT");
+        if (ev && *ev && cfg->step_coop_limit == 0) h->coop_step_limit = atoi(ev) > 0 ? atoi(ev) : 0;
+    }
     // cooperative reset of Handover (one stick): two rows per env, measured cross-over against the lane-pair reset
     if (handover1) {
         h->kp.coop_limit = cfg->reset_coop_limit > 0 ? cfg->reset_coop_limit : (cfg->reset_coop_limit < 0 ? 0 : XARM_HO_RESET_COOP_LIMIT_DEFAULT);
@@ -391,6 +398,16 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                         terminal_obs_dev, h->done_list, cnt);
         else k_ho2_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                         terminal_obs_dev, h->done_list, cnt);
+    }
+    else if (handover && h->cfg.num_obj == 1 && h->kp.num_envs <= (int64_t)h->coop_step_limit) {
+        // small batch: every env on the cooperative rows, one launch (list == null: all envs; finished episodes -> done_list)
+        const unsigned g_ = ho_coop_grid(h->kp.num_envs);
+        if (h->kp.hcfg.use_stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
+        else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(g_), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
+        else k_ho_step_coop_list<xh::HandoverScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
+            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     }
     else if (handover && h->fast_pipeline) {
         // as for PickAndPlace below: every env on the pad-free fast lane-pair step, the ones with an active finger-pad row
@@ -611,7 +628,7 @@ int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, vo
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
                        int32_t *solver_iterations) {
     if (!h || !fast_pipeline || !reset_overlap || !eject_coop_cap || !solver_iterations) return XARM_E_INVALID;
-    const bool small = (h->cfg.env_kind == XARM_ENV_PICK_AND_PLACE || h->cfg.env_kind == XARM_ENV_REACH) && h->kp.num_envs <= (int64_t)h->coop_step_limit;
+    const bool small = h->kp.num_envs <= (int64_t)h->coop_step_limit;   // (the limit is 0 for the env kinds without a cooperative step kernel)
     *fast_pipeline = (h->fast_pipeline && !small) ? 1 : 0;
     *reset_overlap = (*fast_pipeline && h->reset_overlap) ? 1 : 0;
     *eject_coop_cap = h->kp.eject_coop_cap;

@@ -83,7 +83,7 @@ typedef struct xarm_config {
     float same_side_rate;   /* config['same_side_rate'] (Handover, xarm_handover.py:380) */
     int32_t reset_coop_limit; /* PickAndPlace, Reach, Handover (one stick): resets of at most this many envs per call run on the cooperative
                                (16 lanes per env) kernel; 0 = default (XARM_RESET_COOP_LIMIT_DEFAULT), < 0 = never */
-    int32_t step_coop_limit;  /* PickAndPlace, Reach: a handle of at most this many envs also STEPS on the cooperative kernel
+    int32_t step_coop_limit;  /* PickAndPlace, Reach, Handover (one stick): a handle of at most this many envs also STEPS on the cooperative kernel
                                  (the one-env-per-lane launch would leave most SIMDs without a wavefront);
                                  0 = default (XARM_STEP_COOP_LIMIT_DEFAULT), < 0 = never.  Larger PickAndPlace handles step on
                                  the pad-free fast kernel and hand the envs with an active finger-pad row to the cooperative
@@ -112,6 +112,9 @@ typedef struct xarm_config {
  * cooperative rows too. */
 #define XARM_HO_EJECT_COOP_CAP 8192
 #define XARM_HO_RESET_COOP_LIMIT_DEFAULT 4096
+/* ... and a Handover handle of at most XARM_HO_STEP_COOP_LIMIT_DEFAULT envs (step_coop_limit / XARM_STEP_COOP_LIMIT override, as
+ * for PickAndPlace) steps on the cooperative rows altogether: one launch, no fast pass */
+#define XARM_HO_STEP_COOP_LIMIT_DEFAULT 2048
 
 typedef struct xarm_dims_t {
     int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;

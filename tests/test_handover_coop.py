@@ -14,7 +14,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CONT = np.r_[0:36, 38:51]   # q, qd of both arms, object pose and velocity
-FAMILIES = {"lane": dict(step_coop_limit=-1, reset_coop_limit=-1), "fast": {}}
+# kernel families of Handover with one stick: 'lane' = the lane-pair kernels (k_ho_step / k_ho_reset), 'fast' = what a batch of more than
+# 2 048 envs steps on by default (k_ho_step_fast + the hand-off to the cooperative rows; pinned here at the tests' small sizes by
+# step_coop_limit = 1), 'coop' = every env on the cooperative rows (the default for batches of at most 2 048 envs)
+FAMILIES = {"lane": dict(step_coop_limit=-1, reset_coop_limit=-1), "fast": dict(step_coop_limit=1), "coop": {}}
 
 
 @pytest.fixture(scope="module")
@@ -136,7 +139,7 @@ def live(oracle, sharded_handover):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family", ["lane", "fast"])
+@pytest.mark.parametrize("family", ["lane", "fast", "coop"])
 def test_gpu_families_live_oracle_jittered_ezpolicy_256(live, family):
     """every transition of the live fixture replayed on the device from the oracle's state (the
     PickAndPlace thresholds - >= 0.9 of the envs inside the plain bound, <= 0.15 exempt - at EVERY step)"""
@@ -171,7 +174,8 @@ def test_gpu_families_live_oracle_jittered_ezpolicy_256(live, family):
 
 
 @pytest.mark.gpu
-def test_gpu_coop_rows_neighbour_independence_and_forced_coupled(groll):
+@pytest.mark.parametrize("family", ["fast", "coop"])
+def test_gpu_coop_rows_neighbour_independence_and_forced_coupled(groll, family):
     """the hand-off list is filled by atomics, so which two envs share a wavefront varies from run to run: an env's result
     must not depend on its neighbour.  (a) run-to-run and under a permutation of the batch, bitwise; (b) a handle that
     forces every substep through the coupled sweep (XARM_HO_FORCE_COUPLED=1) gives the same bits as the default one."""
@@ -179,7 +183,8 @@ def test_gpu_coop_rows_neighbour_independence_and_forced_coupled(groll):
     import gym_xarm_amd as gx
     from gym_xarm_amd.policies import HandoverEzPolicy
     E = 512
-    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=13, auto_reset=False)
+    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=13, auto_reset=False, **FAMILIES[family])
+    assert env.pipeline_info()["fast_pipeline"] == (family == "fast")
     pol = HandoverEzPolicy()
     obs = env.reset()
     gen = torch.Generator(device="cuda").manual_seed(2)
@@ -191,7 +196,7 @@ def test_gpu_coop_rows_neighbour_independence_and_forced_coupled(groll):
         obs, *_ = env.step(a)
     os.environ["XARM_HO_FORCE_COUPLED"] = "1"
     try:
-        forced = gx.make("XarmPDHandover-v0", num_envs=E, seed=13, auto_reset=False)
+        forced = gx.make("XarmPDHandover-v0", num_envs=E, seed=13, auto_reset=False, **FAMILIES[family])
     finally:
         del os.environ["XARM_HO_FORCE_COUPLED"]
     perm = torch.randperm(E, generator=torch.Generator().manual_seed(5)).cuda()
@@ -235,9 +240,9 @@ def test_gpu_pipeline_against_the_lane_pair_kernel(groll):
     import gym_xarm_amd as gx
     from gym_xarm_amd.policies import HandoverEzPolicy
     E = 2048
-    fast = gx.make("XarmPDHandover-v0", num_envs=E, seed=17, auto_reset=False)
+    fast = gx.make("XarmPDHandover-v0", num_envs=E, seed=17, auto_reset=False, **FAMILIES["fast"])
     lane = gx.make("XarmPDHandover-v0", num_envs=E, seed=17, auto_reset=False, **FAMILIES["lane"])
-    assert fast.kernel_limits()[0] > 0 and lane.kernel_limits() == (0, 0)
+    assert fast.kernel_limits() == (4096, 1) and fast.pipeline_info()["fast_pipeline"] and lane.kernel_limits() == (0, 0)
     pol = HandoverEzPolicy()
     obs = fast.reset()
     lane.reset()
@@ -258,7 +263,7 @@ def test_gpu_pipeline_against_the_lane_pair_kernel(groll):
     fast.close()
     lane.close()
     # auto-reset through the pipeline: every env keeps stepping, finished ones restart with steps = 0 and a new episode id
-    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=3)
+    env = gx.make("XarmPDHandover-v0", num_envs=E, seed=3, **FAMILIES["fast"])
     env.reset()
     s = env.get_state()
     s[:, 74] = torch.arange(E, device="cuda") % 100

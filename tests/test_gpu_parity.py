@@ -336,7 +336,8 @@ def test_world_size_invariance_at_the_baseline_split(gx):
     print("env steps/s at 65 536 envs: default %.3g, reproducible 'fast' pin %.3g" % (rate_default, rates["fast"]))
 
 
-@pytest.mark.parametrize("env_id,E,A", [("XarmPDPickAndPlace-v0", 16384, 4), ("XarmReach-v0", 512, 4), ("XarmPDStackTower-v0", 512, 8)])
+@pytest.mark.parametrize("env_id,E,A", [("XarmPDPickAndPlace-v0", 16384, 4), ("XarmReach-v0", 512, 4), ("XarmPDStackTower-v0", 512, 8),
+                                        ("XarmPDHandover-v0", 4096, 8), ("XarmPDHandover-v0", 512, 8)])   # Handover: the fast pipeline / the cooperative step
 def test_a_captured_step_replays_like_eager_steps(gx, env_id, E, A):
     """xarm_step keeps no host-side per-step state (its device counters are zeroed by a memset inside the call), forks and
     joins its side stream inside the call: one step captured into a HIP graph (torch.cuda.graph) and replayed with new

@@ -418,14 +418,8 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
                                                                                              terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
         else k_ho_step_fast<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                                                   terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
-        if (overlap) {
-            HIPCHK(h, hipEventRecord(h->ev_fork, st));
-            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            launch_ho_reset(h, 2 * grid, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->side);
-            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
-        }
         const int64_t cap = h->kp.num_envs < (int64_t)h->kp.eject_coop_cap ? h->kp.num_envs : (int64_t)h->kp.eject_coop_cap;
-        int *list_b = overlap ? h->done_list_b : h->done_list, *cnt_b = overlap ? h->eject_count + 1 : cnt;
+        int *list_b = h->done_list, *cnt_b = cnt;       // one done list, one reset launch after the hand-off
         if (stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
             h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
         else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
@@ -485,9 +479,8 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
         k_step<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
                                                 terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
     if (timed) HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st));
-    if (h->kp.auto_reset && pipelined && overlap) {
-        if (handover) launch_ho_reset(h, 2 * grid, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
-        else launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
+    if (h->kp.auto_reset && pipelined && overlap) {     // PickAndPlace only (Handover keeps one list, xarm_create)
+        launch_pnp_reset(h, h->done_list_b, h->eject_count + 1, obs_dev, ag_dev, dg_dev, st);
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     } else if (h->kp.auto_reset) {
         if (reach) launch_reach_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, st);

@@ -115,6 +115,8 @@ typedef struct xarm_config {
 /* ... and a Handover handle of at most XARM_HO_STEP_COOP_LIMIT_DEFAULT envs (step_coop_limit / XARM_STEP_COOP_LIMIT override, as
  * for PickAndPlace) steps on the cooperative rows altogether: one launch, no fast pass */
 #define XARM_HO_STEP_COOP_LIMIT_DEFAULT 2048
+/* test hook: XARM_HO_FORCE_COUPLED=1 at xarm_create sends every substep of the cooperative Handover step and reset through the
+ * coupled (both-arms) sweep - same bits by construction (tests/test_handover_coop.py) */
 
 typedef struct xarm_dims_t {
     int32_t obs_dim, goal_dim, act_dim, state_dim, max_episode_steps, n_substeps;

@@ -278,3 +278,36 @@ def test_gpu_pipeline_against_the_lane_pair_kernel(groll):
         assert torch.isfinite(st).all() and (st[d.bool(), 74] == 0).all()
     assert total_done >= 12 * E // 100 - 2 and int((env.get_state()[:, 75] - ep0).sum()) == total_done
     env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_long_hand_off_lists_go_to_the_lane_pair_kernel(groll):
+    """a hand-off list longer than XARM_HO_EJECT_COOP_CAP (8 192 envs: a batch in which nearly every env holds the stick) is stepped
+    by k_ho_step in list mode instead of eight rounds of cooperative wavefronts; under the reproducible 'fast' pin
+    (step_coop_limit = 1) every list stays on the cooperative rows - same envs, float32-close results either way"""
+    import torch
+    import gym_xarm_amd as gx
+    g = groll
+    E = 16384
+    # contact states of the scripted hand-over (arm 1 holding the stick), replicated over the batch
+    holding = g["states"][18][(g["states"][18][:, 62:70] > 0).any(axis=1)]
+    assert holding.shape[0] >= 4
+    st0 = torch.tensor(np.tile(holding, (E // holding.shape[0] + 1, 1))[:E], dtype=torch.float32)
+    a = torch.tensor(np.tile(g["actions"][18][:holding.shape[0]], (E // holding.shape[0] + 1, 1))[:E], dtype=torch.float32) * 0.2
+    outs = {}
+    for tag, kw in (("default", {}), ("pinned", dict(step_coop_limit=1)), ("lane", FAMILIES["lane"])):
+        env = gx.make("XarmPDHandover-v0", num_envs=E, seed=2, auto_reset=False, **kw)
+        env.set_state(st0)
+        env.step(a)
+        outs[tag] = env.get_state().clone()
+        handed = env.debug_counts()[1]
+        cap = env.pipeline_info()["eject_coop_cap"]
+        if tag == "default":
+            assert handed > 8192 == cap, handed                    # the long-list route was really taken
+        if tag == "pinned":
+            assert handed > 8192 and cap == 2 ** 31 - 1
+        env.close()
+    cont = torch.tensor(CONT, device="cuda")
+    assert torch.equal(outs["default"], outs["lane"])             # the list-mode lane-pair kernel IS k_ho_step: same bits per env
+    d = (outs["pinned"] - outs["lane"])[:, cont].abs().max(dim=1).values
+    assert float(d.median()) < 2e-4 and float((d < 2e-3).float().mean()) > 0.9, (float(d.median()), float((d < 2e-3).float().mean()))

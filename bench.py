@@ -65,7 +65,7 @@ WORKLOADS = {
 }
 
 
-COOP_STEP_KERNEL = {"pnp": "k_step_coop", "reach": "k_reach_step_coop"}   # batches <= xarm_config.step_coop_limit
+COOP_STEP_KERNEL = {"pnp": "k_step_coop", "reach": "k_reach_step_coop", "handover": "k_ho_step_coop_list"}   # batches <= xarm_config.step_coop_limit
 
 WORKLOAD_NAMES = {
     "pnp": "XarmPDPickAndPlace-v0 (XarmPickAndPlace, num_obj=1, sparse reward, goal_shape=air)",

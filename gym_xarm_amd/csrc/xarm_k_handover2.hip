@@ -5,8 +5,19 @@
 namespace xd {
 
 // --------------------------------------------------------------------- XarmHandover-v0, num_obj = 2 (two lanes per env)
-// the reference's test.py configuration (test.py:9-15); core xarm_handover2_core.h.  411 LDS floats per lane = 105 KB per
-// wavefront: one wavefront per CU.
+// the reference's test.py configuration (test.py:9-15); core xarm_handover2_core.h.
+// LDS: the arm's columns S | T | A_hh (117 floats) are per lane; the sticks' contact columns (support slots, stick/stick
+// manifold, clipping scratch: 294 floats) are the SAME numbers in an env's two lanes - both compute the object rows
+// redundantly and bit-identically, in lockstep - so the two lanes share one copy: 117 x 64 + 294 x 32 floats = 66 KB per
+// wavefront, two wavefronts per CU (one column set per lane was 105 KB: one wavefront per CU, a quarter of the SIMDs).
+constexpr int H2_OBJ_FLOATS = xh2::LDS_FLOATS - xk::LDS_TBL;
+constexpr int H2_LDS_FLOATS = xk::LDS_TBL * WG + H2_OBJ_FLOATS * (WG / 2);
+struct Ho2Lds {
+    float *arm;   // + lane, column stride WG
+    float *obj;   // + lane / 2, column stride WG / 2
+    __device__ __forceinline__ float &operator[](int i) const { return i < xk::LDS_TBL ? arm[i * WG] : obj[(i - xk::LDS_TBL) * (WG / 2)]; }
+};
+__device__ __forceinline__ Ho2Lds ho2_lds(float *smem) { return Ho2Lds{smem + threadIdx.x, smem + xk::LDS_TBL * WG + (threadIdx.x >> 1)}; }
 __device__ __forceinline__ void h2_load(const KParams &P, int64_t e, int arm, xh2::Lane<float> &L) {
     const float *S = P.state + e;
     const int64_t n = P.stride;
@@ -93,18 +104,18 @@ __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restr
                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                  uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                  int *__restrict__ done_list, int *__restrict__ done_count) {
-    __shared__ float smem[xh2::LDS_FLOATS * WG];
+    __shared__ float smem[H2_LDS_FLOATS];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
     const int arm = (int)(t & 1);
     if (e_in >= P.num_envs) return;
-    DevLds lds{smem + threadIdx.x};
+    const Ho2Lds lds = ho2_lds(smem);
     xh2::Lane<float> L;
     h2_load(P, e_in, arm, L);
     const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in * 2 + arm];
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    xh2::lane_step<float, DevLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg());
+    xh2::lane_step<float, Ho2Lds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg());
     const int64_t e = late_index(e_in);
     h2_store(P, e, arm, L);
     h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -123,22 +134,22 @@ __global__ __launch_bounds__(WG) void k_ho2_step(KParams P, const float *__restr
 template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho2_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                   float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out) {
-    __shared__ float smem[xh2::LDS_FLOATS * WG];
+    __shared__ float smem[H2_LDS_FLOATS];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i = t >> 1;
     const int arm = (int)(t & 1);
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (i >= n) return;
     const int64_t e_in = list ? (int64_t)list[i] : i;
-    DevLds lds{smem + threadIdx.x};
+    const Ho2Lds lds = ho2_lds(smem);
     xh2::Lane<float> L;
     h2_load(P, e_in, arm, L);
-    xh2::lane_reset<float, DevLds, DppXchg, Scene>(P.hcfg, e_in, L, arm, lds, DppXchg());
+    xh2::lane_reset<float, Ho2Lds, DppXchg, Scene>(P.hcfg, e_in, L, arm, lds, DppXchg());
     const int64_t e = late_index(e_in);
     h2_store(P, e, arm, L);
     if (obs_out) h2_write_obs(L, e, arm, obs_out, ag_out, dg_out);
 }
 
-// xarm_handover.py:177-183 over n rows of 6: -sum_i [|ag_i - g_i| > thr]
+// the two scenes the C ABI selects from (xarm_config.use_stand)
 template __global__ void k_ho2_step<xh::HandoverScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                  float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                  float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
@@ -154,6 +165,7 @@ template __global__ void k_ho2_step<xh::HandoverStandScene>(KParams P, const flo
 template __global__ void k_ho2_reset<xh::HandoverStandScene>(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                   float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
 
+// xarm_handover.py:177-183 over n rows of 6: -sum_i [|ag_i - g_i| > thr]
 __global__ void k_ho2_compute_reward(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -256,6 +256,9 @@ def main():
 
     ring_of = {id(env): ring}
     windows, (dt, resets, kstep_ms, reset_ms, launches) = measure(env, args.warmup)
+    if pipe["fast_pipeline"] and hasattr(env, "debug_counts"):
+        # (outside the timed windows: the read synchronises) how many envs the fast kernel handed to the cooperative kernel(s) in the last call
+        pipe = dict(pipe, handed_off_last_call=int(env.debug_counts()[1]))
     total_envs = int(D.sum_over_ranks(E, device=dev))
 
     # extra: the same handle, aged.  An untimed pre-roll, then the same windows.  Random actions knock the objects about,

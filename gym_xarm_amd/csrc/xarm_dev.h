@@ -131,6 +131,23 @@ struct DppXchg {
     __device__ __forceinline__ float partner(float v) const { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); } // quad_perm [1,0,3,2]
 };
 
+// One stage of the staged Handover step (xarm_step, xarm_hip.hip): the fast kernel runs the ticks [tick0, tick1) of the step,
+// the hand-off kernels the ticks [tick0, HO_N_TICKS).  tick0 == 0 opens the step (xh::step_begin) and leaves the joint targets in
+// qt[18][stride] for the later stages; flag[e] != 0: env e was handed off in an earlier stage of this call, the fast kernel
+// passes it by.  The unstaged step is {0, HO_N_TICKS, null, null}.
+struct HoStage {
+    int tick0, tick1;
+    float *qt;
+    uint8_t *flag;
+};
+__device__ __forceinline__ void ho_load_qt(const KParams &P, const HoStage &S, int64_t e, int arm, float (&qt)[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) qt[i] = S.qt[(9 * arm + i) * P.stride + e];
+}
+__device__ __forceinline__ void ho_store_qt(const KParams &P, const HoStage &S, int64_t e, int arm, const float (&qt)[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.qt[(9 * arm + i) * P.stride + e] = qt[i];
+}
 __device__ __forceinline__ void ho_load(const KParams &P, int64_t e, int arm, xh::Lane<float> &L) {
     const float *S = P.state + e;
     const int64_t n = P.stride;
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                const int *__restrict__ list, const int *__restrict__ count);
+                                                const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                  float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);
@@ -266,14 +283,14 @@ __global__ __launch_bounds__(WG) void k_ho_step_fast(KParams P, const float *__r
                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                      uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                      int *__restrict__ done_list, int *__restrict__ done_count,
-                                                     int *__restrict__ eject_list, int *__restrict__ eject_count);
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage);
 template <typename Scene, bool FORCE_COUPLED>
 __global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                           float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
-                                                          const int *__restrict__ list, const int *__restrict__ count);
+                                                          const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 template <typename Scene, bool FORCE_COUPLED>
 __global__ __launch_bounds__(WG) void k_ho_reset_coop(KParams P, const int *__restrict__ list, const int *__restrict__ count,
                                                       float *__restrict__ obs_out, float *__restrict__ ag_out, float *__restrict__ dg_out);

@@ -388,15 +388,22 @@ XARM_HD void substep(const Grp &G, const X &x, const ArmLane<T> &C, EnvState<T> 
     st.bw[0] = wb.x; st.bw[1] = wb.y; st.bw[2] = wb.z;
 }
 
-// XarmHandover.step (:128-139) of one environment on its two rows; L is the row's arm + its copy of the shared state
+// XarmHandover.step (:128-139) of one environment on its two rows; L is the row's arm + its copy of the shared state.
+// env_step_from runs the ticks [tick0, HO_N_TICKS): tick0 == 0 is the whole step, a later one continues the step a fast
+// stage opened (xh::lane_step_fast_range) with the joint targets qt that stage computed.
+template <typename T, typename Lds, typename X, typename Scene = xh::HandoverScene, bool FORCE_COUPLED = false>
+XARM_HD void env_step_from(const Grp &G, const X &x, xh::Lane<T> &L, const T (&act)[4], T (&qt)[9], int tick0, T &reward, bool &done, bool &success,
+                           Lds lds, int reward_type) {
+    const ArmLane<T> C = xc::arm_lane_consts<T>(G);
+    if (tick0 == 0) xh::step_begin(L, x.arm, act, qt);
+#pragma unroll 1
+    for (int k = tick0; k < xm::HO_N_TICKS; k++) substep<T, Lds, X, Scene, FORCE_COUPLED>(G, x, C, L.st, qt, lds);
+    xh::step_end<T, X>(L, x.arm, reward, done, success, x, reward_type);
+}
 template <typename T, typename Lds, typename X, typename Scene = xh::HandoverScene, bool FORCE_COUPLED = false>
 XARM_HD void env_step(const Grp &G, const X &x, xh::Lane<T> &L, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, int reward_type) {
-    const ArmLane<T> C = xc::arm_lane_consts<T>(G);
     T qt[9];
-    xh::step_begin(L, x.arm, act, qt);
-#pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++) substep<T, Lds, X, Scene, FORCE_COUPLED>(G, x, C, L.st, qt, lds);
-    xh::step_end<T, X>(L, x.arm, reward, done, success, x, reward_type);
+    env_step_from<T, Lds, X, Scene, FORCE_COUPLED>(G, x, L, act, qt, 0, reward, done, success, lds, reward_type);
 }
 
 // XarmHandover.reset (:141-145, _reset_sim :338-368, _sample_goal :370-393); same sequence as xh::lane_reset

@@ -280,32 +280,46 @@ XARM_HD void step_end(const Lane<T> &L, int arm, T &reward, bool &done, bool &su
     done = success || ((int)L.st.steps == xm::HO_MAX_EPISODE_STEPS);
 }
 
+// Ticks [tick0, tick1) of XarmHandover.step: tick0 == 0 opens the step (action -> joint targets qt, friction toggle, stick
+// clamp: step_begin), a later tick0 continues it with the qt the opening stage left; tick1 == HO_N_TICKS closes it (reward,
+// done, success: step_end).  The staged hand-off of xarm_step (xarm_hip.hip) cuts a step into stages so that an env whose
+// finger pads come alive in stage c re-runs only the ticks from that stage's first one on the cooperative rows.
 // act = this arm's 4 action entries (:249-256)
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
+XARM_HD void lane_step_range(Lane<T> &L, int arm, const T (&act)[4], T (&qt)[9], int tick0, int tick1, T &reward, bool &done, bool &success,
+                             Lds lds, Xchg x, int reward_type = 0) {
+    if (tick0 == 0) step_begin(L, arm, act, qt);
+#pragma unroll 1
+    for (int k = tick0; k < tick1; k++) tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
+    if (tick1 == xm::HO_N_TICKS) step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
+}
 template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD void lane_step(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
     T qt[9];
-    step_begin(L, arm, act, qt);
-#pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++) tick<T, Lds, Xchg, Scene>(L, qt, lds, arm, x);
-    step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
+    lane_step_range<T, Lds, Xchg, Scene>(L, arm, act, qt, 0, xm::HO_N_TICKS, reward, done, success, lds, x, reward_type);
 }
 
 // The same step on the pad-free fast substep (xk::substep<.., FAST>: no finger-pad rows, nothing of the arm in LDS, no
 // exchange inside the sweep - without pad rows the two arms never interact and the object-only rows are computed
-// identically by both lanes).  Returns false when a finger-pad row of EITHER arm was active in any of the 15 ticks: the
-// outputs are then meaningless and the caller must not store them (the environment is stepped again, from its untouched
-// state, by the cooperative kernel: xarm_handover_coop_core.h).
+// identically by both lanes).  Returns false when a finger-pad row of EITHER arm was active in any of the ticks run: the
+// outputs are then meaningless and the caller must not store them (the environment is stepped again, from the untouched
+// state it had before these ticks, by the cooperative kernel: xarm_handover_coop_core.h).
+template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
+XARM_HD bool lane_step_fast_range(Lane<T> &L, int arm, const T (&act)[4], T (&qt)[9], int tick0, int tick1, T &reward, bool &done, bool &success,
+                                  Lds lds, Xchg x, int reward_type = 0) {
+    if (tick0 == 0) step_begin(L, arm, act, qt);
+    bool pad = false;
+#pragma unroll 1
+    for (int k = tick0; k < tick1; k++)
+        pad = xk::substep<T, Lds, Scene, Xchg, true>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x) || pad;
+    if (tick1 == xm::HO_N_TICKS) step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
+    const bool other = x.partner(pad ? (T)1 : (T)0) != (T)0;
+    return !(pad || other);
+}
 template <typename T, typename Lds, typename Xchg, typename Scene = HandoverScene>
 XARM_HD bool lane_step_fast(Lane<T> &L, int arm, const T (&act)[4], T &reward, bool &done, bool &success, Lds lds, Xchg x, int reward_type = 0) {
     T qt[9];
-    step_begin(L, arm, act, qt);
-    bool pad = false;
-#pragma unroll 1
-    for (int k = 0; k < xm::HO_N_TICKS; k++)
-        pad = xk::substep<T, Lds, Scene, Xchg, true>(L.st, qt, (T)xm::HO_TIME_STEP, lds, arm, x) || pad;
-    step_end<T, Xchg>(L, arm, reward, done, success, x, reward_type);
-    const bool other = x.partner(pad ? (T)1 : (T)0) != (T)0;
-    return !(pad || other);
+    return lane_step_fast_range<T, Lds, Xchg, Scene>(L, arm, act, qt, 0, xm::HO_N_TICKS, reward, done, success, lds, x, reward_type);
 }
 
 } // namespace xh

@@ -45,6 +45,15 @@ struct xarm_handle {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     int reset_overlap;
+    // staged Handover step (xarm_step): the fast lane-pair kernel runs the step's 15 ticks in ho_stages launches; the envs a stage
+    // hands off re-run only the ticks from that stage's first one on the cooperative rows, on a side stream beside the next stage
+    static constexpr int MAX_ST = 5;
+    int ho_stages;        // 1 = one fast launch, one hand-off (round 4's first pipeline)
+    int ho_tick[MAX_ST + 1]; // stage c runs the ticks [ho_tick[c], ho_tick[c + 1])
+    float *ho_qt;         // [18][stride] joint targets of the step the first stage opened
+    uint8_t *ho_flag;     // [stride] handed off in an earlier stage of this call
+    hipStream_t st_side[MAX_ST];
+    hipEvent_t st_fork[MAX_ST], st_join[MAX_ST];
     int ho_force_coupled; // test hook (XARM_HO_FORCE_COUPLED=1): every substep of the cooperative Handover step through the coupled sweep
     // StackTower: class-homogeneous wavefronts (xarm_stack_core.h class_layout); null when XARM_ST_CLASS_ORDER=0
     uint8_t *class_key;  // [E] row-set class of each env's last substep
@@ -78,6 +87,17 @@ static int fail(xarm_handle *h, int code, const char *fmt, const char *detail) {
 static unsigned ho_coop_grid(int64_t cap) {
     const int64_t g = (cap + xhc::ROW_ENVS - 1) / xhc::ROW_ENVS;
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+// XarmHandover.step of the envs list[0 .. *count) (null: all) on the cooperative rows, from tick stage.tick0 on
+static void launch_ho_coop_step(xarm_handle *h, unsigned g_, const float *actions_dev, float *obs_dev, float *ag_dev, float *dg_dev, float *reward_dev,
+                                uint8_t *done_dev, uint8_t *success_dev, float *terminal_obs_dev, int *done_list, int *done_count,
+                                const int *list, const int *count, HoStage stage, hipStream_t st) {
+    if (h->kp.hcfg.use_stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
+        h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, done_list, done_count, list, count, stage);
+    else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(g_), dim3(WG), 0, st>>>(
+        h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, done_list, done_count, list, count, stage);
+    else k_ho_step_coop_list<xh::HandoverScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
+        h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, done_list, done_count, list, count, stage);
 }
 // Handover reset of the envs in list[0 .. *count) (null: all): the cooperative rows take counts up to kp.coop_limit, the lane-pair
 // kernel the rest; both are launched, the one out of its range exits at once (the count lives on the device)
@@ -237,6 +257,25 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         if (ev && *ev) h->fast_pipeline = h->fast_pipeline && atoi(ev) != 0;
         ev = getenv("XARM_HO_FORCE_COUPLED");
         h->ho_force_coupled = ev && *ev && atoi(ev) != 0;
+        // staged Handover step: XARM_HO_STAGES=1 is the unstaged pipeline (one fast launch, one hand-off)
+        h->ho_stages = handover1 && h->fast_pipeline ? XARM_HO_STAGES_DEFAULT : 1;
+        ev = getenv("XARM_HO_STAGES");
+        if (ev && *ev && handover1 && h->fast_pipeline) h->ho_stages = atoi(ev) < 1 ? 1 : (atoi(ev) > xarm_handle::MAX_ST ? xarm_handle::MAX_ST : atoi(ev));
+        for (int c = 0; c <= h->ho_stages; c++) h->ho_tick[c] = c * xm::HO_N_TICKS / h->ho_stages;
+        // measurement hook: XARM_HO_STAGE_TICKS="3,9" = the interior stage boundaries (increasing, inside 1 .. 14)
+        ev = getenv("XARM_HO_STAGE_TICKS");
+        if (ev && *ev && h->ho_stages > 1) {
+            int c = 1, prev = 0;
+            const char *q = ev;
+            while (*q && c < h->ho_stages) {
+                const int v = atoi(q);
+                if (v <= prev || v >= xm::HO_N_TICKS) break;
+                h->ho_tick[c++] = prev = v;
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+            if (c != h->ho_stages) for (int k = 0; k <= h->ho_stages; k++) h->ho_tick[k] = k * xm::HO_N_TICKS / h->ho_stages;   // malformed: the default
+        }
     }
     h->kp.eject_coop_cap = handover1 ? XARM_HO_EJECT_COOP_CAP : XARM_EJECT_COOP_CAP;
     // step_coop_limit == 1 is the pin of reproducible_limits('fast'): every hand-off list steps on the cooperative kernel (it
@@ -254,11 +293,11 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->kp.rcfg.reward_type = cfg->reward_type;
     hipError_t e1 = hipMalloc(&h->kp.state, sizeof(float) * h->kp.state_dim * stride);
     hipError_t e2 = hipMalloc(&h->done_list, sizeof(int) * stride);
-    hipError_t e3 = hipMalloc(&h->counters, sizeof(int) * (3 + 2 * xs::NCLS));
+    hipError_t e3 = hipMalloc(&h->counters, sizeof(int) * (3 + 2 * xs::NCLS));   // (Handover: +3 + c = hand-off count of stage c >= 1)
     h->done_count = h->counters; h->eject_count = h->counters + 1; h->class_hist = h->counters + 3;
     hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
     if (e4 == hipSuccess && h->fast_pipeline) {
-        e4 = hipMalloc(&h->eject_list, sizeof(int) * stride);
+        e4 = hipMalloc(&h->eject_list, sizeof(int) * stride * (handover1 ? h->ho_stages : 1));   // one list per stage
         if (e4 == hipSuccess) e4 = hipMalloc(&h->done_list_b, sizeof(int) * stride);
         const char *ev = getenv("XARM_RESET_OVERLAP");
         // (PickAndPlace only: Handover's reset is six single-substep ticks, 0.28 ms whether it runs beside the hand-off or after
@@ -268,6 +307,20 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
             if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
             if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
             h->reset_overlap = e4 == hipSuccess;
+        }
+    }
+    if (e4 == hipSuccess && h->fast_pipeline && handover1 && h->ho_stages > 1) {
+        e4 = hipMalloc(&h->ho_qt, sizeof(float) * 18 * stride);
+        if (e4 == hipSuccess) e4 = hipMalloc(&h->ho_flag, stride);
+        if (e4 == hipSuccess) e4 = hipMemset(h->ho_flag, 0, stride);
+        for (int c = 0; c + 1 < h->ho_stages && e4 == hipSuccess; c++) {
+            const char *pv = getenv("XARM_HO_SIDE_PRIO");
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = the LEAST urgent (numerically greatest)
+            if (pv && *pv && atoi(pv) != 0) e4 = hipStreamCreateWithPriority(&h->st_side[c], hipStreamNonBlocking, lo);
+            else e4 = hipStreamCreateWithFlags(&h->st_side[c], hipStreamNonBlocking);
+            if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->st_fork[c], hipEventDisableTiming);
+            if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&h->st_join[c], hipEventDisableTiming);
         }
     }
     if (e4 == hipSuccess && stack) {
@@ -318,6 +371,13 @@ int xarm_destroy(xarm_handle *h) {
     if (h->side) hipStreamDestroy(h->side);
     if (h->class_key) hipFree(h->class_key);
     if (h->class_order) hipFree(h->class_order);
+    if (h->ho_qt) hipFree(h->ho_qt);
+    if (h->ho_flag) hipFree(h->ho_flag);
+    for (int c = 0; c < xarm_handle::MAX_ST; c++) {
+        if (h->st_fork[c]) hipEventDestroy(h->st_fork[c]);
+        if (h->st_join[c]) hipEventDestroy(h->st_join[c]);
+        if (h->st_side[c]) hipStreamDestroy(h->st_side[c]);
+    }
     delete h;
     return XARM_OK;
 }
@@ -375,6 +435,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     if (timed) HIPCHK(h, hipEventRecord(h->ev0[h->ev_n], st));
     const bool reach = h->cfg.env_kind == XARM_ENV_REACH, handover = h->cfg.env_kind == XARM_ENV_HANDOVER;
     const bool stack = h->cfg.env_kind == XARM_ENV_STACK_TOWER;
+    const HoStage whole{0, xm::HO_N_TICKS, nullptr, nullptr};   // Handover: an unstaged step
     if (h->kp.auto_reset == XARM_AUTO_RESET_LAZY) {
         k_step_lazy<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev);
         if (timed) { HIPCHK(h, hipEventRecord(h->ev1[h->ev_n], st)); HIPCHK(h, hipEventRecord(h->ev2[h->ev_n], st)); h->ev_n++; }
@@ -383,7 +444,7 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     }
     // the call's device-side counters (ended episodes, hand-offs, class histogram): zeroed here, in stream order - the
     // handle keeps no host-side per-step state, so a captured step call replays correctly
-    HIPCHK(h, hipMemsetAsync(h->counters, 0, sizeof(int) * ((stack && h->class_key) ? 3 + 2 * xs::NCLS : (h->fast_pipeline ? 3 : 1)), st));
+    HIPCHK(h, hipMemsetAsync(h->counters, 0, sizeof(int) * ((stack && h->class_key) ? 3 + 2 * xs::NCLS : (h->fast_pipeline ? (h->ho_stages > 1 ? 4 + xarm_handle::MAX_ST : 3) : 1)), st));
     if (stack) {
         if (h->class_key) {
             const unsigned cg = (unsigned)((h->kp.num_envs + 255) / 256);
@@ -401,44 +462,53 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     }
     else if (handover && h->cfg.num_obj == 1 && h->kp.num_envs <= (int64_t)h->coop_step_limit) {
         // small batch: every env on the cooperative rows, one launch (list == null: all envs; finished episodes -> done_list)
-        const unsigned g_ = ho_coop_grid(h->kp.num_envs);
-        if (h->kp.hcfg.use_stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
-        else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(g_), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
-        else k_ho_step_coop_list<xh::HandoverScene, false><<<dim3(g_), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
+        launch_ho_coop_step(h, ho_coop_grid(h->kp.num_envs), actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev,
+                            h->done_list, cnt, nullptr, nullptr, whole, st);
     }
     else if (handover && h->fast_pipeline) {
         // as for PickAndPlace below: every env on the pad-free fast lane-pair step, the ones with an active finger-pad row
-        // handed off, untouched, to the cooperative rows (lists of at most eject_coop_cap envs) or to k_ho_step (longer)
+        // handed off, untouched, to the cooperative rows (lists of at most eject_coop_cap envs) or to k_ho_step (longer).
+        // STAGED: the fast kernel runs the 15 ticks in ho_stages launches.  An env whose pads come alive in stage c keeps the
+        // state it had before that stage and re-runs the ticks from the stage's first one on the cooperative rows - on a side
+        // stream, beside the next fast stage (16 384 envs are 512 of the 1 024 SIMDs); only the last stage's hand-off, a third
+        // of a step long, is on the critical path: fast 0.73 + hand-off 0.69 ms became 0.77 + 0.27.
         pipelined = true;
         const bool stand = h->kp.hcfg.use_stand != 0;
-        if (stand) k_ho_step_fast<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                                                             terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
-        else k_ho_step_fast<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                                                  terminal_obs_dev, h->done_list, cnt, h->eject_list, h->eject_count);
+        const int nst = h->ho_stages;
         const int64_t cap = h->kp.num_envs < (int64_t)h->kp.eject_coop_cap ? h->kp.num_envs : (int64_t)h->kp.eject_coop_cap;
-        int *list_b = h->done_list, *cnt_b = cnt;       // one done list, one reset launch after the hand-off
-        if (stand) k_ho_step_coop_list<xh::HandoverStandScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
-        else if (h->ho_force_coupled) k_ho_step_coop_list<xh::HandoverScene, true><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
-        else k_ho_step_coop_list<xh::HandoverScene, false><<<dim3(ho_coop_grid(cap)), dim3(WG), 0, st>>>(
-            h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
-        if (h->kp.num_envs > cap) {
-            if (stand) k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                                                            terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
-            else k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
-                                                                                 terminal_obs_dev, list_b, cnt_b, h->eject_list, h->eject_count);
+        for (int c = 0; c < nst; c++) {
+            const HoStage sg{h->ho_tick[c], h->ho_tick[c + 1], h->ho_qt, h->ho_flag};
+            int *elist = h->eject_list + (int64_t)c * h->kp.stride, *ecnt = c == 0 ? h->eject_count : h->counters + 3 + c;
+            if (stand) k_ho_step_fast<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                                 terminal_obs_dev, h->done_list, cnt, elist, ecnt, sg);
+            else k_ho_step_fast<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                      terminal_obs_dev, h->done_list, cnt, elist, ecnt, sg);
+            hipStream_t hs = st;
+            if (c + 1 < nst) {
+                hs = h->st_side[c];
+                HIPCHK(h, hipEventRecord(h->st_fork[c], st));
+                HIPCHK(h, hipStreamWaitEvent(hs, h->st_fork[c], 0));
+            }
+            // one done list for every kernel of the call (atomic appends), one reset launch after the last hand-off
+            const HoStage rest{sg.tick0, xm::HO_N_TICKS, h->ho_qt, h->ho_flag};
+            launch_ho_coop_step(h, ho_coop_grid(cap), actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev,
+                                h->done_list, cnt, elist, ecnt, rest, hs);
+            if (h->kp.num_envs > cap) {
+                if (stand) k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, hs>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                                terminal_obs_dev, h->done_list, cnt, elist, ecnt, rest);
+                else k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, hs>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                                     terminal_obs_dev, h->done_list, cnt, elist, ecnt, rest);
+            }
+            if (c + 1 < nst) HIPCHK(h, hipEventRecord(h->st_join[c], hs));
         }
+        for (int c = 0; c + 1 < nst; c++) HIPCHK(h, hipStreamWaitEvent(st, h->st_join[c], 0));
     }
     else if (handover && h->kp.hcfg.use_stand)
         k_ho_step<xh::HandoverStandScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                           success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
+                                                                           success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr, whole);
     else if (handover)
         k_ho_step<xh::HandoverScene><<<dim3(2 * grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev,
-                                                                      success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr);
+                                                                      success_dev, terminal_obs_dev, h->done_list, cnt, nullptr, nullptr, whole);
     else if (reach && h->kp.num_envs <= (int64_t)h->coop_step_limit)
         k_reach_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
             h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt);
@@ -611,11 +681,12 @@ int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t 
 int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, void *stream) {
     if (!h || !finished || !handed_off) return XARM_E_INVALID;
     DEVGUARD(h);
-    int c[2] = {0, 0};
+    int c[4 + xarm_handle::MAX_ST] = {0};
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(h, hipMemcpy(c, h->counters, sizeof c, hipMemcpyDeviceToHost));
     *finished = c[0];
     *handed_off = h->fast_pipeline ? c[1] : 0;
+    for (int k = 1; k < h->ho_stages; k++) *handed_off += c[3 + k];   // staged Handover step: one list per stage
     return XARM_OK;
 }
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,

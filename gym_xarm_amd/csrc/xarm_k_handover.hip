@@ -21,7 +21,7 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                const int *__restrict__ list, const int *__restrict__ count) {
+                                                const int *__restrict__ list, const int *__restrict__ count, HoStage stage) {
     __shared__ float smem[xk::LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, i_in = t >> 1;
     const int arm = (int)(t & 1);
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(WG) void k_ho_step(KParams P, const float *__restri
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    xh::lane_step<float, DevLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
+    float qt[9];
+    if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, arm, qt);   // the step was opened by an earlier fast stage
+    xh::lane_step_range<float, DevLds, DppXchg, Scene>(L, arm, act, qt, stage.tick0, xm::HO_N_TICKS, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
     const int64_t e = late_index(e_in);
     ho_store(P, e, arm, L);
     ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
@@ -57,13 +59,13 @@ template __global__ void k_ho_step<xh::HandoverScene>(KParams P, const float *__
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                const int *__restrict__ list, const int *__restrict__ count);
+                                                const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 template __global__ void k_ho_step<xh::HandoverStandScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                 float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                 float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                 uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                 int *__restrict__ done_list, int *__restrict__ done_count,
-                                                const int *__restrict__ list, const int *__restrict__ count);
+                                                const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 
 template <typename Scene>
 __global__ __launch_bounds__(WG) void k_ho_reset(KParams P, const int *__restrict__ list, const int *__restrict__ count,
@@ -108,11 +110,12 @@ __global__ __launch_bounds__(WG) void k_ho_step_fast(KParams P, const float *__r
                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                      uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                      int *__restrict__ done_list, int *__restrict__ done_count,
-                                                     int *__restrict__ eject_list, int *__restrict__ eject_count) {
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage) {
     __shared__ float smem[FAST_LDS_FLOATS * WG];
     const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x, e_in = t >> 1;
     const int arm = (int)(t & 1);
     if (e_in >= P.num_envs) return;
+    if (stage.tick0 > 0 && stage.flag[e_in]) return;   // handed off in an earlier stage of this call
     FastLds lds{smem + threadIdx.x};
     xh::Lane<float> L;
     ho_load(P, e_in, arm, L);
@@ -120,16 +123,27 @@ __global__ __launch_bounds__(WG) void k_ho_step_fast(KParams P, const float *__r
     const float act[4] = {a4.x, a4.y, a4.z, a4.w};
     float reward;
     bool done, success;
-    const bool ok = xh::lane_step_fast<float, FastLds, DppXchg, Scene>(L, arm, act, reward, done, success, lds, DppXchg(), P.hcfg.reward_type);
+    float qt[9];
+    if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, arm, qt);
+    const bool ok = xh::lane_step_fast_range<float, FastLds, DppXchg, Scene>(L, arm, act, qt, stage.tick0, stage.tick1, reward, done, success, lds,
+                                                                            DppXchg(), P.hcfg.reward_type);
     const int64_t e = late_index(e_in);
     if (!ok) {
         if (arm == 0) {
             const int pos = atomicAdd(eject_count, 1);
             eject_list[pos] = (int)e;
+            if (stage.flag) stage.flag[e] = 1;
         }
         return;
     }
     ho_store(P, e, arm, L);
+    if (stage.tick1 < xm::HO_N_TICKS) {   // the step goes on in the next stage
+        if (stage.tick0 == 0) {
+            ho_store_qt(P, stage, e, arm, qt);
+            if (arm == 0) stage.flag[e] = 0;
+        }
+        return;
+    }
     ho_write_obs(L, e, arm, obs_out, ag_out, dg_out);
     if (done && P.auto_reset && term_obs) ho_write_obs(L, e, arm, term_obs, ag_out, dg_out);
     if (arm == 0) {
@@ -148,12 +162,12 @@ template __global__ void k_ho_step_fast<xh::HandoverScene>(KParams P, const floa
                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                      uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                      int *__restrict__ done_list, int *__restrict__ done_count,
-                                                     int *__restrict__ eject_list, int *__restrict__ eject_count);
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage);
 template __global__ void k_ho_step_fast<xh::HandoverStandScene>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                      float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                      uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                      int *__restrict__ done_list, int *__restrict__ done_count,
-                                                     int *__restrict__ eject_list, int *__restrict__ eject_count);
+                                                     int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage);
 
 } // namespace xd

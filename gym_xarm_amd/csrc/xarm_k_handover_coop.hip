@@ -36,7 +36,7 @@ __global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float
                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
-                                                          const int *__restrict__ list, const int *__restrict__ count) {
+                                                          const int *__restrict__ list, const int *__restrict__ count, HoStage stage) {
     __shared__ float smem[HO_COOP_LDS_FLOATS * WG];
     const int64_t n = count ? (int64_t)*count : P.num_envs;
     if (count && n > P.eject_coop_cap) return;
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(WG) void k_ho_step_coop_list(KParams P, const float
         const float act[4] = {a4.x, a4.y, a4.z, a4.w};
         float reward;
         bool done, success;
-        xhc::env_step<float, DevLds, SwapXchg, Scene, FORCE_COUPLED>(G, x, L, act, reward, done, success, lds, P.hcfg.reward_type);
+        float qt[9];
+        if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, x.arm, qt);   // the step was opened by an earlier fast stage
+        xhc::env_step_from<float, DevLds, SwapXchg, Scene, FORCE_COUPLED>(G, x, L, act, qt, stage.tick0, reward, done, success, lds, P.hcfg.reward_type);
         if (live && G.l == 0) {
             const int64_t e = late_index(e_in);
             ho_store(P, e, x.arm, L);
@@ -80,19 +82,19 @@ template __global__ void k_ho_step_coop_list<xh::HandoverScene, false>(KParams P
                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
-                                                          const int *__restrict__ list, const int *__restrict__ count);
+                                                          const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 template __global__ void k_ho_step_coop_list<xh::HandoverScene, true>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                           float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
-                                                          const int *__restrict__ list, const int *__restrict__ count);
+                                                          const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 template __global__ void k_ho_step_coop_list<xh::HandoverStandScene, false>(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
                                                           float *__restrict__ ag_out, float *__restrict__ dg_out,
                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                           uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                           int *__restrict__ done_list, int *__restrict__ done_count,
-                                                          const int *__restrict__ list, const int *__restrict__ count);
+                                                          const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 
 // XarmHandover.reset on the cooperative rows for the envs list[0 .. *count) (null: all), counts up to P.coop_limit (more:
 // k_ho_reset, launched beside this kernel): six ticks of latency for the handful of envs that finish in a step

@@ -115,6 +115,13 @@ typedef struct xarm_config {
 /* ... and a Handover handle of at most XARM_HO_STEP_COOP_LIMIT_DEFAULT envs (step_coop_limit / XARM_STEP_COOP_LIMIT override, as
  * for PickAndPlace) steps on the cooperative rows altogether: one launch, no fast pass */
 #define XARM_HO_STEP_COOP_LIMIT_DEFAULT 2048
+/* The Handover pipeline is STAGED: the fast kernel runs the 15 ticks of a step in XARM_HO_STAGES_DEFAULT launches (env
+ * XARM_HO_STAGES = 1 .. 5 at xarm_create; 1 = one fast launch and one hand-off).  An env whose pads come alive in stage c keeps the
+ * state it had before that stage and re-runs the ticks from the stage's first one on the cooperative rows, on a side stream
+ * owned by the handle, beside the next fast stage; every side stream is joined (event wait) before the call's work on the
+ * caller's stream ends.  Which kernel runs which tick of an env is a function of that env's own state and of the handle's
+ * configuration, never of its neighbours. */
+#define XARM_HO_STAGES_DEFAULT 3
 /* test hook: XARM_HO_FORCE_COUPLED=1 at xarm_create sends every substep of the cooperative Handover step and reset through the
  * coupled (both-arms) sweep - same bits by construction (tests/test_handover_coop.py) */
 

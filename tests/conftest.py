@@ -224,10 +224,11 @@ class HostCore:
                            self._p(obs), self._p(ag), self._p(dg))
         return st, obs, ag, dg
 
-    def hoc_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1, rt=0, use_stand=0, mode="coop"):
+    def hoc_step(self, state, actions, f32=1, seed=0, off=0, ssr=0.5, gs=1, rt=0, use_stand=0, mode="coop", stages=3):
         """XarmHandover.step on the cooperative rows (csrc/xarm_handover_coop_core.h; mode 'coop', 'coupled' = every substep
         forced through the coupled sweep) or on the pad-free fast lane pair (mode 'fast'); returns ok[e] last: False = a pad
-        row was active during the fast step and row e came back untouched"""
+        row was active during the fast step and row e came back untouched.  mode 'staged': the staged pipeline of xarm_step
+        with `stages` fast stages; the last return value is then 0 (finished on the fast path) or 1 + the stage that handed off"""
         E = state.shape[0]
         self.L.xh_ho_set_reward_type(C.c_int(rt))
         self.L.xh_ho_set_use_stand(C.c_int(use_stand))
@@ -235,9 +236,9 @@ class HostCore:
         a = np.ascontiguousarray(actions, dtype=np.float64)
         obs, ag, dg = np.zeros((E, 29)), np.zeros((E, 3)), np.zeros((E, 3))
         rew, done, succ, ok = np.zeros(E), np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.ones(E, np.uint8)
-        self.L.xh_hoc_step(C.c_int(f32), C.c_int({"coop": 0, "coupled": 2, "fast": 4}[mode]), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs),
+        self.L.xh_hoc_step(C.c_int(f32), C.c_int({"coop": 0, "coupled": 2, "fast": 4, "staged": 4 + int(stages)}[mode]), C.c_uint64(seed), C.c_int64(off), C.c_double(ssr), C.c_int(gs),
                            C.c_int64(E), self._p(st), self._p(a), self._p(obs), self._p(ag), self._p(dg), self._p(rew), self._u8(done), self._u8(succ), self._u8(ok))
-        return st, obs, ag, dg, rew, done, succ, ok.astype(bool)
+        return st, obs, ag, dg, rew, done, succ, (ok.astype(np.int64) if mode == "staged" else ok.astype(bool))
 
     def hoc_reset(self, state, mask=None, f32=1, seed=0, off=0, ssr=0.5, gs=1, use_stand=0, forced=False):
         E = state.shape[0]

@@ -340,7 +340,7 @@ struct RowXchg {
     }
 };
 template <typename T> struct HocJob {
-    int mode;   // 0 step, 1 reset, 2 step forced through the coupled sweep, 3 reset forced coupled, 4 the fast lane-pair step
+    int mode;   // 0 step, 1 reset, 2 step forced through the coupled sweep, 3 reset forced coupled, 4 the fast lane-pair step, 4 + n the staged pipeline with n stages
     xh::EnvCfg cfg; int64_t E; double *state; const double *act; const uint8_t *mask;
     double *obs, *ag, *dg, *rew; uint8_t *done, *succ, *ok; PairShared *psh; RowShared *rsh; int arm;
 };
@@ -351,12 +351,32 @@ template <typename T, typename Scene> void hoc_env(HocJob<T> &J, int64_t e) {
     xh::Lane<T> L; T lds[xk::LDS_FLOATS]; HostLds<T> hl{lds};
     hload(J.state + e * xh::STATE_DIM, J.arm, L);
     T r = 0; bool d = false, su = false, ok = true;
+    int stage = 0;   // staged modes: 1 + the stage that handed the env off
     T a[4] = {0, 0, 0, 0};
     if (J.act) for (int k = 0; k < 4; k++) a[k] = (T)J.act[e * 8 + 4 * J.arm + k];
     if (J.mode == 0) xhc::env_step<T, HostLds<T>, RowXchg, Scene, false>(G, x, L, a, r, d, su, hl, J.cfg.reward_type);
     else if (J.mode == 2) xhc::env_step<T, HostLds<T>, RowXchg, Scene, true>(G, x, L, a, r, d, su, hl, J.cfg.reward_type);
     else if (J.mode == 1) xhc::env_reset<T, HostLds<T>, RowXchg, Scene, false>(G, x, J.cfg, e, L, hl);
     else if (J.mode == 3) xhc::env_reset<T, HostLds<T>, RowXchg, Scene, true>(G, x, J.cfg, e, L, hl);
+    else if (J.mode >= 5) {
+        // the staged pipeline of xarm_step (xarm_hip.hip) with J.mode - 4 stages: fast ticks stage by stage from the last accepted
+        // state; the first stage that reports a pad row is dropped and the cooperative rows run the ticks from its first one on
+        const int nst = J.mode - 4, N = xm::HO_N_TICKS;
+        T qt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < nst; c++) {
+            xh::Lane<T> L2 = L;
+            T qt2[9];
+            for (int k = 0; k < 9; k++) qt2[k] = qt[k];
+            if (xh::lane_step_fast_range<T, HostLds<T>, PairXchg, Scene>(L2, J.arm, a, qt2, c * N / nst, (c + 1) * N / nst, r, d, su, hl, px, J.cfg.reward_type)) {
+                L = L2;
+                for (int k = 0; k < 9; k++) qt[k] = qt2[k];
+            } else {
+                xhc::env_step_from<T, HostLds<T>, RowXchg, Scene, false>(G, x, L, a, qt, c * N / nst, r, d, su, hl, J.cfg.reward_type);
+                stage = 1 + c;
+                break;
+            }
+        }
+    }
     else ok = xh::lane_step_fast<T, HostLds<T>, PairXchg, Scene>(L, J.arm, a, r, d, su, hl, px, J.cfg.reward_type);
     T o8[8];
     xh::arm_obs(L, J.arm, o8);
@@ -371,7 +391,7 @@ template <typename T, typename Scene> void hoc_env(HocJob<T> &J, int64_t e) {
             if (J.rew) { J.rew[e] = r; J.done[e] = d; J.succ[e] = su; }
         }
     }
-    if (J.arm == 0 && J.ok) J.ok[e] = ok;
+    if (J.arm == 0 && J.ok) J.ok[e] = J.mode >= 5 ? (uint8_t)stage : (uint8_t)ok;
     J.rsh->bar.wait();
 }
 template <typename T> void *hoc_thread(void *p) {
@@ -412,7 +432,8 @@ void xh_ho_reset(int f32, uint64_t seed, int64_t off, double ssr, int gs, int64_
     auto c = hcfg(seed, off, ssr, gs);
     if (f32) ho_run<float>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0); else ho_run<double>(1, c, E, state, 0, mask, obs, ag, dg, 0, 0, 0);
 }
-// mode: 0 cooperative rows, 2 cooperative rows forced through the coupled sweep, 4 the pad-free fast lane-pair step (ok[e] = 0: a pad row was active, row e untouched)
+// mode: 0 cooperative rows, 2 cooperative rows forced through the coupled sweep, 4 the pad-free fast lane-pair step (ok[e] = 0: a pad row was active, row e untouched),
+// 4 + n the staged pipeline of xarm_step with n stages (ok[e] = 0: finished on the fast path, 1 + c: handed off in stage c)
 void xh_hoc_step(int f32, int mode, uint64_t seed, int64_t off, double ssr, int gs, int64_t E, double *state, const double *act, double *obs, double *ag, double *dg, double *rew, uint8_t *done, uint8_t *succ, uint8_t *ok) {
     auto c = hcfg(seed, off, ssr, gs);
     if (f32) hoc_run<float>(mode, c, E, state, act, 0, obs, ag, dg, rew, done, succ, ok); else hoc_run<double>(mode, c, E, state, act, 0, obs, ag, dg, rew, done, succ, ok);

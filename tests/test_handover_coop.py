@@ -88,6 +88,35 @@ def test_hostcore_fast_step_equals_lane_pair_on_accepted_envs(hostcore, groll):
     assert 0.3 < n_ok / n < 0.9       # the fixture holds both kinds
 
 
+def test_hostcore_staged_pipeline_f64_equals_oracle_and_hands_off_late_contacts_late(hostcore, groll):
+    """the staged step of xarm_step (three fast stages of five ticks; the stage that sees a pad row is dropped and the cooperative
+    rows run the ticks from its first one on) in float64 == the oracle through the scripted hand-over, like each core alone;
+    envs are handed off in every stage (a contact that begins late in the step is handed off late), and with one stage the
+    staged step is the fast step on the envs that one accepts and the cooperative step on the others, bit for bit"""
+    g = groll
+    seen = np.zeros(4, np.int64)
+    for t in range(0, g["actions"].shape[0], 2):
+        S, A = g["states"][t], g["actions"][t]
+        st, obs, ag, dg, rew, done, succ, stage = hostcore.hoc_step(S, A, f32=0, seed=2, mode="staged", stages=3)
+        ok = g["sens"][t] < 1e-2
+        err = np.abs(st - g["states"][t + 1]).max(axis=1)
+        assert (err[ok] <= 1e-9 + 1e-3 * g["sens"][t][ok]).all(), (t, err[ok].max())
+        np.testing.assert_allclose(obs[ok], g["obs"][t][ok], atol=1e-7)
+        assert np.array_equal(rew[ok], g["rew"][t][ok]) and np.array_equal(done[ok], g["done"][t][ok])
+        seen += np.bincount(stage, minlength=4)
+    assert (seen > 0).all(), seen        # fast path, and a hand-off in each of the three stages
+    for t in (3, 17, 29):
+        S, A = g["states"][t], g["actions"][t]
+        for f32 in (0, 1):
+            one = hostcore.hoc_step(S, A, f32=f32, seed=2, mode="staged", stages=1)
+            fast = hostcore.hoc_step(S, A, f32=f32, seed=2, mode="fast")
+            coop = hostcore.hoc_step(S, A, f32=f32, seed=2)
+            acc = fast[7]
+            assert np.array_equal(one[7] == 0, acc)
+            for k in range(7):
+                assert np.array_equal(one[k][acc], fast[k][acc]) and np.array_equal(one[k][~acc], coop[k][~acc]), (t, f32, k)
+
+
 def test_hostcore_dense_reward_and_stand_on_the_coop_rows(oracle, hostcore, groll):
     g = groll
     sub = slice(0, 8)

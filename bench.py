@@ -259,6 +259,8 @@ def main():
     if pipe["fast_pipeline"] and hasattr(env, "debug_counts"):
         # (outside the timed windows: the read synchronises) how many envs the fast kernel handed to the cooperative kernel(s) in the last call
         pipe = dict(pipe, handed_off_last_call=int(env.debug_counts()[1]))
+    if hasattr(env, "stage_info") and args.workload == "handover":
+        pipe = dict(pipe, handover_stage_ticks=env.stage_info())
     total_envs = int(D.sum_over_ranks(E, device=dev))
 
     # extra: the same handle, aged.  An untimed pre-roll, then the same windows.  Random actions knock the objects about,

@@ -17,7 +17,7 @@ GOAL_SHAPES = {"air": 0, "ground": 1}
 RESET_COOP_LIMIT_DEFAULT = STEP_COOP_LIMIT_DEFAULT = 8192   # include/xarm_hip.h XARM_*_COOP_LIMIT_DEFAULT
 
 EXPORTS = ["xarm_create", "xarm_destroy", "xarm_dims", "xarm_reset", "xarm_step", "xarm_compute_reward",
-           "xarm_get_state", "xarm_set_state", "xarm_episode_steps", "xarm_debug_substeps", "xarm_timing_enable", "xarm_timing_read", "xarm_timing_read_reset", "xarm_kernel_limits", "xarm_pipeline_info", "xarm_debug_counts", "xarm_class_keys", "xarm_last_error",
+           "xarm_get_state", "xarm_set_state", "xarm_episode_steps", "xarm_debug_substeps", "xarm_timing_enable", "xarm_timing_read", "xarm_timing_read_reset", "xarm_kernel_limits", "xarm_pipeline_info", "xarm_stage_info", "xarm_debug_counts", "xarm_class_keys", "xarm_last_error",
            "xarm_version"]
 
 
@@ -70,6 +70,7 @@ def load(path=None):
     L.xarm_timing_read_reset.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.xarm_kernel_limits.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.xarm_pipeline_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.xarm_stage_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.xarm_debug_counts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.xarm_class_keys.argtypes = [vp, vp, vp]
     L.xarm_last_error.argtypes = [vp]

@@ -47,7 +47,7 @@ struct xarm_handle {
     int reset_overlap;
     // staged Handover step (xarm_step): the fast lane-pair kernel runs the step's 15 ticks in ho_stages launches; the envs a stage
     // hands off re-run only the ticks from that stage's first one on the cooperative rows, on a side stream beside the next stage
-    static constexpr int MAX_ST = 5;
+    static constexpr int MAX_ST = XARM_HO_MAX_STAGES;
     int ho_stages;        // 1 = one fast launch, one hand-off (round 4's first pipeline)
     int ho_tick[MAX_ST + 1]; // stage c runs the ticks [ho_tick[c], ho_tick[c + 1])
     float *ho_qt;         // [18][stride] joint targets of the step the first stage opened
@@ -687,6 +687,15 @@ int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, vo
     *finished = c[0];
     *handed_off = h->fast_pipeline ? c[1] : 0;
     for (int k = 1; k < h->ho_stages; k++) *handed_off += c[3 + k];   // staged Handover step: one list per stage
+    return XARM_OK;
+}
+int xarm_stage_info(const xarm_handle *h, int32_t *stages, int32_t *ticks) {
+    if (!h || !stages || !ticks) return XARM_E_INVALID;
+    const bool staged = h->fast_pipeline && h->ho_stages > 1 && h->kp.num_envs > (int64_t)h->coop_step_limit;
+    *stages = staged ? h->ho_stages : 1;
+    for (int c = 0; c <= XARM_HO_MAX_STAGES; c++) ticks[c] = 0;
+    if (staged) for (int c = 0; c <= h->ho_stages; c++) ticks[c] = h->ho_tick[c];
+    else if (h->cfg.env_kind == XARM_ENV_HANDOVER) ticks[1] = xm::HO_N_TICKS;
     return XARM_OK;
 }
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,

@@ -192,9 +192,14 @@ int xarm_kernel_limits(const xarm_handle *h, int32_t *reset_coop_limit, int32_t 
  *                    xarm_version() says "TIMING VARIANT") */
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,
                        int32_t *solver_iterations);
+/* The stages of the staged Handover step (XARM_HO_STAGES_DEFAULT above): *stages = their number (1 for a handle without the
+ * staged pipeline), ticks[0 .. *stages] = the first tick of each stage and, last, the tick count of a step; ticks has room for
+ * XARM_HO_MAX_STAGES + 1 entries */
+#define XARM_HO_MAX_STAGES 5
+int xarm_stage_info(const xarm_handle *h, int32_t *stages, int32_t *ticks);
 /* development / test hook: the device-side counters of the LAST xarm_step call, after synchronising `stream` - episodes that
  * ended in the step kernels (a pipelined PickAndPlace call counts the ones that ended in the hand-off apart: not included) and
- * envs handed off by the fast kernel to the cooperative one (0 for a handle without the pipeline) */
+ * envs handed off by the fast kernel to the cooperative one (0 for a handle without the pipeline; the staged Handover step: all stages) */
 int xarm_debug_counts(xarm_handle *h, int32_t *finished, int32_t *handed_off, void *stream);
 
 /* StackTower: the row-set class each env's last substep fell into, uint8 [E] (bits 0-2 cube pairs (0,1) (0,2) (1,2) in

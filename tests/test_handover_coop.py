@@ -310,6 +310,49 @@ def test_gpu_pipeline_against_the_lane_pair_kernel(groll):
 
 
 @pytest.mark.gpu
+def test_gpu_staged_step_against_the_unstaged_pipeline(groll, monkeypatch):
+    """the staged step (three fast launches of five ticks, each stage's hand-off re-running the ticks from that stage's first one on
+    the cooperative rows beside the next stage; the default) against the unstaged pipeline (XARM_HO_STAGES=1: one fast launch, one
+    hand-off): an env that finishes on the fast path or is handed off in the first stage runs the same kernels over the same ticks
+    - the same bits; an env whose pads come alive later in the step (handed off in stage 1 or 2) has its first ticks on the lane-pair
+    core instead of the cooperative one - float32-close.  Run to run the staged step is bitwise reproducible (three streams)."""
+    import torch
+    import gym_xarm_amd as gx
+    from gym_xarm_amd.policies import HandoverEzPolicy
+    E = 4096
+    staged = gx.make("XarmPDHandover-v0", num_envs=E, seed=23, auto_reset=False)
+    monkeypatch.setenv("XARM_HO_STAGES", "1")
+    plain = gx.make("XarmPDHandover-v0", num_envs=E, seed=23, auto_reset=False)
+    monkeypatch.delenv("XARM_HO_STAGES")
+    assert staged.stage_info() == [0, 5, 10, 15] and plain.stage_info() == [0, 15]
+    assert staged.pipeline_info()["fast_pipeline"] and plain.pipeline_info()["fast_pipeline"]
+    pol = HandoverEzPolicy()
+    obs = staged.reset()
+    cont = torch.tensor(CONT, device="cuda")
+    n_same = n_late = n_handed = 0
+    for t in range(40):
+        a = pol(obs) if t % 2 == 0 else torch.rand(E, 8, device="cuda") * 2 - 1
+        st0 = staged.get_state().clone()
+        plain.set_state(st0)
+        obs, rew, done, _ = staged.step(a)
+        ref, handed = staged.get_state().clone(), staged.debug_counts()[1]
+        pobs, prew, pdone, _ = plain.step(a)
+        same = (ref == plain.get_state()).all(dim=1)
+        d = (ref - plain.get_state())[:, cont].abs().max(dim=1).values
+        # (no bound on the worst env: a contact that BEGINS in the step amplifies the float32 difference of the ticks before it - the
+        # sensitivity the oracle tests measure and exempt, oracle/parity.py)
+        assert float((d < 1e-3).float().mean()) > 0.99 and float((d < 5e-2).float().mean()) > 0.998, (t, float(d.max()), float((d < 1e-3).float().mean()))
+        assert torch.equal(rew[same], prew[same]) and torch.equal(done[same], pdone[same]) and torch.equal(obs["observation"][same], pobs["observation"][same])
+        n_same += int(same.sum()); n_late += int((~same).sum()); n_handed += handed
+        staged.set_state(st0)
+        staged.step(a)
+        assert torch.equal(staged.get_state(), ref)                       # run to run
+    assert n_handed > 40 * E // 50 and 0 < n_late < n_handed and n_same > 0.9 * 40 * E, (n_same, n_late, n_handed)
+    staged.close()
+    plain.close()
+
+
+@pytest.mark.gpu
 def test_gpu_long_hand_off_lists_go_to_the_lane_pair_kernel(groll):
     """a hand-off list longer than XARM_HO_EJECT_COOP_CAP (8 192 envs: a batch in which nearly every env holds the stick) is stepped
     by k_ho_step in list mode instead of eight rounds of cooperative wavefronts; under the reproducible 'fast' pin

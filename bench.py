@@ -379,6 +379,11 @@ def main():
             except Exception:
                 pmc_data = {}
         traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (kernel_name, E))
+        # the staged Handover step launches its fast kernel once per stage: the PMC figure is the average of ONE launch
+        step_launches = max(1, len(pipe.get("handover_stage_ticks", [0, 0])) - 1)
+        traffic_one_launch = traffic
+        if traffic and step_launches > 1:
+            traffic = traffic * step_launches
         # secondary ceiling (the one that actually binds): fp32 vector issue.  FLOPs per env step are COUNTED (the
         # kernel core instantiated with a counting scalar type, tools/count_flops.py -> profiles/flop_count.json);
         # the wave-instruction count of the committed SQ_INSTS_VALU pass is kept beside it
@@ -389,6 +394,8 @@ def main():
         flops = pmc_data.get("%s_counted_flops_per_env_step" % args.workload)
         flops_reset = pmc_data.get("%s_counted_flops_per_env_reset" % args.workload)
         n_valu = pmc_data.get("%s_valu_wave_insts_per_launch_%d" % (kernel_name, E))
+        if n_valu and step_launches > 1:
+            n_valu = n_valu * step_launches      # (per call: the PMC figure is the average of one of the stage launches)
         resets_per_call = resets / max(args.steps, 1) / world
         if flops:
             tf_step = flops * E / (kstep_ms * 1e-3) / 1e12
@@ -471,6 +478,10 @@ def main():
             "library": {"version": lib_version, "path": lib_path, "variant": variant, "pipeline": pipe,
                         "reset_coop_limit": reset_limit, "step_coop_limit": step_limit},
         }
+        if step_launches > 1:
+            out["roofline"]["kernels"][kernel_name].update(launches_per_call=step_launches, traffic_one_launch=traffic_one_launch,
+                note="%d fast stages per call (ticks %s); `traffic` = %d x the PMC average of one launch, each stage reads and writes the state" % (
+                    step_launches, pipe["handover_stage_ticks"], step_launches))
         if valu is not None:
             out["roofline"]["valu"] = valu
         if aged is not None:

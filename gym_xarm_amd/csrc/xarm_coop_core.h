@@ -195,8 +195,9 @@ template <typename T> struct Setup {
     T tvt[NTS], tl0[NTS];
     int tid[NTS];
     T m_vt[9], la_vt[7], la_sg[7], lf_vt[2][2], g_vt;
-    V3<T> pp[NP], pn[NP], pt1[NP]; // pad points: position, normal, first tangent
-    T pvt[NP], pl0[NP];
+    // pad points, DEALT to the lanes: lane l holds pad l / 3 (the pad whose row (l / 3, l % 3) it owns; lanes 12-15 repeat pad 3):
+    // position, normal, first tangent, target velocity, warm start.  Only the flags are shared by the row.
+    LV<T> lpp[3], lpn[3], lpt1[3], lpvt, lpl0;
     bool pact[NP];
     bool pad_any, la_any;
     T pad_cfm, mu_p;
@@ -259,15 +260,15 @@ XARM_HD void lane_rows_base(const Setup<T> &S, int l, T (&R)[R_N]) {
 }
 
 template <typename T, typename Lds, bool PAD, bool LA>
-XARM_HD void lane_rows_extra(const Setup<T> &S, Lds lds, int l, T (&R)[R_N]) {
-    // slot 2: pad row (idx, a) on lanes 0..11
+XARM_HD void lane_rows_extra(const Setup<T> &S, Lds lds, int l, int li, T (&R)[R_N]) {
+    // slot 2: pad row (idx, a) on lanes 0..11; li = the lane's slot in the LV fields (0 on the device, l on the host)
     if (PAD) {
         const int idx = l / 3, a = l - 3 * idx;
         const bool own = l < NF;
         const int fk = idx / xm::NPAD;
-        const V3<T> p = selv4(idx, S.pp[0], S.pp[1], S.pp[2], S.pp[3]);
-        const V3<T> n = selv4(idx, S.pn[0], S.pn[1], S.pn[2], S.pn[3]);
-        const V3<T> t1 = selv4(idx, S.pt1[0], S.pt1[1], S.pt1[2], S.pt1[3]);
+        const V3<T> p = mk<T>(S.lpp[0].v[li], S.lpp[1].v[li], S.lpp[2].v[li]);
+        const V3<T> n = mk<T>(S.lpn[0].v[li], S.lpn[1].v[li], S.lpn[2].v[li]);
+        const V3<T> t1 = mk<T>(S.lpt1[0].v[li], S.lpt1[1].v[li], S.lpt1[2].v[li]);
         const V3<T> t2 = cross(n, t1);
         const V3<T> d = selv3(a, n, t1, t2);
         const V3<T> mo = cross(p, d);
@@ -289,9 +290,9 @@ XARM_HD void lane_rows_extra(const Setup<T> &S, Lds lds, int l, T (&R)[R_N]) {
         R[R_J2B + 0] = own ? -d.x : (T)0; R[R_J2B + 1] = own ? -d.y : (T)0; R[R_J2B + 2] = own ? -d.z : (T)0;
         R[R_J2B + 3] = own ? -rd.x : (T)0; R[R_J2B + 4] = own ? -rd.y : (T)0; R[R_J2B + 5] = own ? -rd.z : (T)0;
         ju += R[R_J2B + 0] * S.vb.x + R[R_J2B + 1] * S.vb.y + R[R_J2B + 2] * S.vb.z + R[R_J2B + 3] * S.wb.x + R[R_J2B + 4] * S.wb.y + R[R_J2B + 5] * S.wb.z;
-        const T vt = a == 0 ? sel4(idx, S.pvt[0], S.pvt[1], S.pvt[2], S.pvt[3]) : (T)0;
+        const T vt = a == 0 ? S.lpvt.v[li] : (T)0;
         R[R_G + 2] = own ? vt - ju : (T)0;
-        R[R_L0 + 2] = (own && a == 0) ? sel4(idx, S.pl0[0], S.pl0[1], S.pl0[2], S.pl0[3]) : (T)0;
+        R[R_L0 + 2] = (own && a == 0) ? S.lpl0.v[li] : (T)0;
         R[R_CFM] = (own && a == 0) ? S.pad_cfm : (T)0;
     }
     // slot 3: arm joint limit i on lanes 0..6
@@ -939,13 +940,18 @@ XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, c
     const T pad_denom = dt * (T)xm::FINGER_CONTACT_STIFFNESS + (T)(xm::FINGER_CONTACT_DAMPING + xm::OBJECT_CONTACT_DAMPING);
     const T pad_erp = dt * (T)xm::FINGER_CONTACT_STIFFNESS / pad_denom;
     S.pad_cfm = ((T)1 / pad_denom) * idt;
-    S.pad_any = false;
-    bool touch_f[2] = {false, false};
-#pragma unroll
-    for (int idx = 0; idx < NP; idx++) {
-        const int fk = idx / xm::NPAD, j = idx % xm::NPAD;
+    // DEALT: each lane tests the ONE pad whose rows it owns (lane l: pad l / 3; lanes 12-15 repeat pad 3) instead of all four in
+    // every lane, and keeps the point for its own row; only the flags travel (four row broadcasts each)
+    static_assert(xm::NPAD == 2 && NP == 4, "pad dealing below");
+    LV<T> actf, tchf;
+    XC_LANES {
+        const int l = lane_of(G, i_);
+        const int idx = l / 3 < NP ? l / 3 : NP - 1;
+        const int fk = idx >> 1, j = idx & 1;
         const T sg = fk == 0 ? (T)1 : (T)-1;
-        const V3<T> c = AD.fo[fk] + hc0 * (T)xm::PAD_C[j][0] + hc1 * (sg * (T)xm::PAD_C[j][1]) + hc2 * (T)xm::PAD_C[j][2];
+        const T pc0 = j == 0 ? (T)xm::PAD_C[0][0] : (T)xm::PAD_C[1][0], pc1 = j == 0 ? (T)xm::PAD_C[0][1] : (T)xm::PAD_C[1][1];
+        const T pc2 = j == 0 ? (T)xm::PAD_C[0][2] : (T)xm::PAD_C[1][2];
+        const V3<T> c = xk::selv(fk == 0, AD.fo[0], AD.fo[1]) + hc0 * pc0 + hc1 * (sg * pc1) + hc2 * pc2;
         const V3<T> d = c - cb;
         const V3<T> cl = mk<T>(dot(b0, d), dot(b1, d), dot(b2, d));
         const V3<T> ql = mk<T>(clampT(cl.x, -hx, hx), clampT(cl.y, -hy, hy), clampT(cl.z, -hz, hz));
@@ -971,15 +977,21 @@ XARM_HD void substep_setup(const Grp &G, const ArmLane<T> &C, EnvState<T> &st, c
             pl = mk<T>(k == 0 ? s1 * hx : cl.x, k == 1 ? s1 * hy : cl.y, k == 2 ? s1 * hz : cl.z);
         }
         const bool act = dist < (T)xm::SOLVER_MARGIN;
-        touch_f[fk] = touch_f[fk] || (dist < (T)xm::CONTACT_MARGIN);
-        S.pad_any = S.pad_any || act;
-        S.pact[idx] = act;
-        S.pn[idx] = b0 * nl.x + b1 * nl.y + b2 * nl.z;
-        S.pp[idx] = cb + b0 * pl.x + b1 * pl.y + b2 * pl.z;
-        S.pt1[idx] = xk::plane_space(S.pn[idx]);
-        S.pvt[idx] = dist < (T)0 ? -pad_erp * dist * idt : -dist * idt;
-        S.pl0[idx] = act ? (T)xm::WARMSTART * st.lam_p[idx] : (T)0;
+        actf.v[i_] = act ? (T)1 : (T)0;
+        tchf.v[i_] = dist < (T)xm::CONTACT_MARGIN ? (T)1 : (T)0;
+        const V3<T> pn = b0 * nl.x + b1 * nl.y + b2 * nl.z;
+        const V3<T> pp = cb + b0 * pl.x + b1 * pl.y + b2 * pl.z;
+        const V3<T> pt1 = xk::plane_space(pn);
+        S.lpn[0].v[i_] = pn.x; S.lpn[1].v[i_] = pn.y; S.lpn[2].v[i_] = pn.z;
+        S.lpp[0].v[i_] = pp.x; S.lpp[1].v[i_] = pp.y; S.lpp[2].v[i_] = pp.z;
+        S.lpt1[0].v[i_] = pt1.x; S.lpt1[1].v[i_] = pt1.y; S.lpt1[2].v[i_] = pt1.z;
+        S.lpvt.v[i_] = dist < (T)0 ? -pad_erp * dist * idt : -dist * idt;
+        S.lpl0.v[i_] = act ? (T)xm::WARMSTART * sel4(idx, st.lam_p[0], st.lam_p[1], st.lam_p[2], st.lam_p[3]) : (T)0;
     }
+    S.pact[0] = lv_get<0>(actf) != (T)0; S.pact[1] = lv_get<3>(actf) != (T)0;
+    S.pact[2] = lv_get<6>(actf) != (T)0; S.pact[3] = lv_get<9>(actf) != (T)0;
+    S.pad_any = S.pact[0] || S.pact[1] || S.pact[2] || S.pact[3];
+    const bool touch_f[2] = {lv_get<0>(tchf) != (T)0 || lv_get<3>(tchf) != (T)0, lv_get<6>(tchf) != (T)0 || lv_get<9>(tchf) != (T)0};
     S.mu_p = (T)xm::MU_OBJECT * (st.mug > (T)0.5 ? (T)xm::MU_FINGER_GRASP : (T)xm::MU_FINGER);
     // the touch flag is an output of the collision pass
     st.touch = (touch_f[0] && touch_f[1]) ? (T)1 : (T)0;
@@ -1017,7 +1029,7 @@ XARM_HD void build_extra(const Grp &G, const Setup<T> &S, Lds lds, Sweep<T> &W, 
         for (int k = 0; k < C2_N; k++) a2[k] = (T)0;
 #pragma unroll
         for (int k = 0; k < 4; k++) iv[k] = (T)0;
-        lane_rows_extra<T, Lds, PAD, LA>(S, lds, l, R);
+        lane_rows_extra<T, Lds, PAD, LA>(S, lds, l, i_, R);
         lane_delassus_extra<T, PAD, LA, Scene>(S, l, R, a1, a2, a3, iv);
 #pragma unroll
         for (int k = R_J2A; k < R_G; k++) J[k].v[i_] = R[k];

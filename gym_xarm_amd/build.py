@@ -26,7 +26,10 @@ UNIT_FLAGS = {}
 # the contact-path tick from 2.36 to 2.05 ms (tools/variant_time.sh; disabling post-RA scheduling costs +33 %).  Its
 # price: it raises register pressure until ~42 dwords of per-env state are parked in scratch across each substep's
 # sweep (168 B/lane, outside the Gauss-Seidel loop; +19 MB of L2<->fabric traffic per 65 536-env launch).
-# XARM_SCHED=default builds with LLVM's default scheduler instead (0 B scratch, ~13 % slower).
+# XARM_SCHED=default builds with LLVM's default scheduler instead (0 B scratch, ~13 % slower).  Re-checked in round 4 for the
+# lane-pair kernels of StackTower / two-stick Handover (k_st_step 3.95 ms, k_ho2_step 4.55 ms with iterative-ilp): default 4.30 / 5.38,
+# max-ilp 4.34 / 5.41, max-memory-clause 4.38 / 5.36, iterative-minreg 4.98 / 5.74 ms - although every one of them emits ~100 fewer
+# VALU instructions per sweep: what they add is s_waitcnt stalls (147 -> 243-302 per sweep), and a lone wavefront has nothing to hide them.
 _SCHED = [] if os.environ.get("XARM_SCHED", "ilp") == "default" else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize"] + _SCHED
 

@@ -516,6 +516,13 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
 #undef XC_COLL
     }
     const LV<T> mu_tv = lv_fill_vgpr(mu_t), mu_pv = lv_fill(mu_p);
+    // NL[i]: the impulse pair pair step i last produced.  Only lane i's entry means anything (the other lanes clamp their own c),
+    // and only lane i's entry is ever used: its difference to the new pair is what step i broadcasts.  Keeping the 14 pairs
+    // in registers replaces the per-step write of lane i into ONE pair (two v_cndmask_b32 per step: 8 of the 48 cycles of a pair
+    // step, tools/probes/commit_probe.hip) by 14 writes after the last sweep - same values, same arithmetic.
+    LV2<T> NL[NA1];
+#pragma unroll
+    for (int i = 0; i < NA1; i++) NL[i] = lam01;
     // which arm-limit rows are live somewhere in the wavefront (usually one joint near one limit): the others are
     // exact no-ops and are skipped, the launch lasts as long as its slowest wavefront
     bool law[NLA];
@@ -532,8 +539,8 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
             if ((i) % 3 == 0 || (i) >= NT) nx = lv_max0(nx);                                                 \
             else nx = lv_med3(nx, lv_neg(lim), lim);                                                         \
             const LV2<T> nl = lv2_make(nx, lv_med3(lv2_y(c01), W.lo1, W.hi1));                               \
-            const LV2<T> dl = lv2_sub(nl, lam01);                                                            \
-            lv2_commit<i>(G, lam01, nl);                                                                     \
+            const LV2<T> dl = lv2_sub(nl, NL[i]);                                                            \
+            NL[i] = nl; /* no commit inside the loop: see NL above */                                        \
             if ((i) % 3 == 0 && (i) < NT) lim = lv_mul(lv_bcast<i>(nx), mu_tv); /* friction limit of this point */ \
             const LV2<T> b = lv2_bcast<i>(dl);                                                               \
             c01 = lv2_fma(A01[i], b, c01);                                                                   \
@@ -578,6 +585,10 @@ XARM_HD void sweep_all(const Grp &G, Sweep<T> &W, T mu_t, T mu_p, const bool (&p
 #undef XC_F_ROW
 #undef XC_F_PAD
     }
+#define XC_KEEP(i) lv2_commit<i>(G, lam01, NL[i]);
+    XC_KEEP(0) XC_KEEP(1) XC_KEEP(2) XC_KEEP(3) XC_KEEP(4) XC_KEEP(5) XC_KEEP(6) XC_KEEP(7) XC_KEEP(8) XC_KEEP(9)
+    XC_KEEP(10) XC_KEEP(11) XC_KEEP(12) XC_KEEP(13)
+#undef XC_KEEP
     W.lam[0] = lv2_x(lam01);
     W.lam[1] = lv2_y(lam01);
 }

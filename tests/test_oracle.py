@@ -230,3 +230,37 @@ def test_dense_reward_matches_reference_golden(oracle, golden_reward):
                                         g["dense_goal"][i], m) for i in range(len(g["dense_reward"]))])
     np.testing.assert_allclose(out, g["dense_reward"], rtol=0, atol=1e-15)
     assert len(set(np.round(out, 3))) > 50 and (out == 0.5).any() and (out > 1.0).any()
+
+
+def test_parity_compare_rule_and_its_guard_band():
+    """oracle/parity.py compare(): plain bound, sensitivity allowance capped at 1e-2, exemption above SENS_EXEMPT, and the bounded
+    guard-band allowance of the live Handover batch (an env just under the exemption line may miss the cap by up to 10 x its
+    measured sensitivity, if such envs are at most `band_outliers` of the batch) - off by default"""
+    from oracle import parity as P
+    E = 200
+    ref = np.zeros((E, 4))
+    sens = np.full(E, 1e-7)
+    x = ref + 1e-4
+    assert P.compare(x, ref, sens)["frac_tight"] == 1.0
+    x2 = x.copy(); x2[3] = 2e-3                                    # over the plain bound, no sensitivity to explain it
+    with pytest.raises(AssertionError):
+        P.compare(x2, ref, sens)
+    s2 = sens.copy(); s2[3] = 1e-5                                 # 300 x 1e-5 = 3e-3 allowance
+    assert P.compare(x2, ref, s2)["frac_ok"] == 1.0
+    x3 = x.copy(); x3[3] = 0.5; s3 = sens.copy(); s3[3] = 2 * P.SENS_EXEMPT      # exempt and counted
+    st = P.compare(x3, ref, s3)
+    assert st["frac_exempt"] == 1.0 / E and st["frac_ok"] == 1.0
+    x4 = x.copy(); x4[3] = 0.02; s4 = sens.copy(); s4[3] = 0.93 * P.SENS_EXEMPT  # the live Handover case: 6.5 x sens, cap is 1e-2
+    with pytest.raises(AssertionError):
+        P.compare(x4, ref, s4)                                     # strict by default
+    st = P.compare(x4, ref, s4, band_outliers=1.0 / E)
+    assert st["frac_ok"] == 1.0 and st["frac_ok_strict"] == 1.0 - 1.0 / E
+    x5 = x4.copy(); x5[7] = 0.02; s5 = s4.copy(); s5[7] = s4[3]
+    with pytest.raises(AssertionError):
+        P.compare(x5, ref, s5, band_outliers=1.0 / E)              # two such envs are one too many
+    x6 = x.copy(); x6[3] = 0.05
+    with pytest.raises(AssertionError):
+        P.compare(x6, ref, s4, band_outliers=1.0 / E)              # 16 x sens is not explained by the guard band
+    s7 = sens.copy(); s7[3] = 0.2 * P.SENS_EXEMPT
+    with pytest.raises(AssertionError):
+        P.compare(x4, ref, s7, band_outliers=1.0 / E)              # far below the line there is no band

@@ -850,21 +850,31 @@ XARM_HD void substep(Lane<T> &L, const T dt, Lds lds, const int arm, const Xchg 
                     dq8 += lds[LDS_T + 8 * 6 + k] * wtot[k];
                 }
             }
+            // hand the cube velocities over.  Three wave-uniform cases, the same values as one select cascade over all of them (which cost
+            // 36 instructions per cube and sweep in every wavefront, pads or not): sequential - take arm 0's after phase 0, arm 1's after
+            // phase 1; concurrent with a pad somewhere in the wavefront - take the partner's where only it touched; no pad at all - nothing
+            if (ph == 0) {
+                if (seq) {
 #pragma unroll
-            for (int o = 0; o < NOBJ; o++) {
-                if (ph == 0) {
-                    const bool take = ((othermask >> o) & 1) != 0;   // concurrent: the partner lane touched cube o, this one did not
-                    const V3<T> f0 = mk<T>(xchg.from0(vb[o].x), xchg.from0(vb[o].y), xchg.from0(vb[o].z));
-                    const V3<T> g0 = mk<T>(xchg.from0(wb[o].x), xchg.from0(wb[o].y), xchg.from0(wb[o].z));
-                    const V3<T> pv = mk<T>(xchg.partner(vb[o].x), xchg.partner(vb[o].y), xchg.partner(vb[o].z));
-                    const V3<T> pw = mk<T>(xchg.partner(wb[o].x), xchg.partner(wb[o].y), xchg.partner(wb[o].z));
-                    vb[o] = selv(seq, f0, selv(take, pv, vb[o]));
-                    wb[o] = selv(seq, g0, selv(take, pw, wb[o]));
-                } else {
-                    const V3<T> f1 = mk<T>(xchg.from1(vb[o].x), xchg.from1(vb[o].y), xchg.from1(vb[o].z));
-                    const V3<T> g1 = mk<T>(xchg.from1(wb[o].x), xchg.from1(wb[o].y), xchg.from1(wb[o].z));
-                    vb[o] = selv(seq, f1, vb[o]);
-                    wb[o] = selv(seq, g1, wb[o]);
+                    for (int o = 0; o < NOBJ; o++) {
+                        vb[o] = mk<T>(xchg.from0(vb[o].x), xchg.from0(vb[o].y), xchg.from0(vb[o].z));
+                        wb[o] = mk<T>(xchg.from0(wb[o].x), xchg.from0(wb[o].y), xchg.from0(wb[o].z));
+                    }
+                } else if (XARM_ANY(mymask != 0 || othermask != 0)) {
+#pragma unroll
+                    for (int o = 0; o < NOBJ; o++) {
+                        const bool take = ((othermask >> o) & 1) != 0;   // the partner lane touched cube o, this one did not
+                        const V3<T> pv = mk<T>(xchg.partner(vb[o].x), xchg.partner(vb[o].y), xchg.partner(vb[o].z));
+                        const V3<T> pw = mk<T>(xchg.partner(wb[o].x), xchg.partner(wb[o].y), xchg.partner(wb[o].z));
+                        vb[o] = selv(take, pv, vb[o]);
+                        wb[o] = selv(take, pw, wb[o]);
+                    }
+                }
+            } else if (seq) {
+#pragma unroll
+                for (int o = 0; o < NOBJ; o++) {
+                    vb[o] = mk<T>(xchg.from1(vb[o].x), xchg.from1(vb[o].y), xchg.from1(vb[o].z));
+                    wb[o] = mk<T>(xchg.from1(wb[o].x), xchg.from1(wb[o].y), xchg.from1(wb[o].z));
                 }
             }
         }

@@ -259,8 +259,10 @@ def main():
     if pipe["fast_pipeline"] and hasattr(env, "debug_counts"):
         # (outside the timed windows: the read synchronises) how many envs the fast kernel handed to the cooperative kernel(s) in the last call
         pipe = dict(pipe, handed_off_last_call=int(env.debug_counts()[1]))
-    if hasattr(env, "stage_info") and args.workload == "handover":
-        pipe = dict(pipe, handover_stage_ticks=env.stage_info())
+    if hasattr(env, "stage_info") and args.workload in ("handover", "pnp"):
+        pipe = dict(pipe, stage_ticks=env.stage_info())
+        if args.workload == "pnp" and pipe["fast_pipeline"] and len(pipe["stage_ticks"]) > 2:
+            kernel_name, handoff_kernel = "k_step_fast_stage", "k_step_coop_list_stage"      # the staged step's own kernels (xarm_k_pnp.hip)
     total_envs = int(D.sum_over_ranks(E, device=dev))
 
     # extra: the same handle, aged.  An untimed pre-roll, then the same windows.  Random actions knock the objects about,
@@ -379,8 +381,8 @@ def main():
             except Exception:
                 pmc_data = {}
         traffic = pmc_data.get("%s_hbm_bytes_per_launch_%d" % (kernel_name, E))
-        # the staged Handover step launches its fast kernel once per stage: the PMC figure is the average of ONE launch
-        step_launches = max(1, len(pipe.get("handover_stage_ticks", [0, 0])) - 1)
+        # the staged step (Handover, PickAndPlace) launches its fast kernel once per stage: the PMC figure is the average of ONE launch
+        step_launches = max(1, len(pipe.get("stage_ticks", [0, 0])) - 1)
         traffic_one_launch = traffic
         if traffic and step_launches > 1:
             traffic = traffic * step_launches
@@ -481,7 +483,7 @@ def main():
         if step_launches > 1:
             out["roofline"]["kernels"][kernel_name].update(launches_per_call=step_launches, traffic_one_launch=traffic_one_launch,
                 note="%d fast stages per call (ticks %s); `traffic` = %d x the PMC average of one launch, each stage reads and writes the state" % (
-                    step_launches, pipe["handover_stage_ticks"], step_launches))
+                    step_launches, pipe["stage_ticks"], step_launches))
         if valu is not None:
             out["roofline"]["valu"] = valu
         if aged is not None:

@@ -1222,4 +1222,16 @@ XARM_HD void env_step(const Grp &G, const EnvCfg &cfg, EnvState<T> &st, const T 
     done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
 }
 
+// substeps [k0, 15) of a step on a 16-lane row: k0 == 0 is env_step, a later one continues the step a fast stage opened (xk::env_step_fast_range)
+template <typename T, typename Lds>
+XARM_HD void env_step_from(const Grp &G, const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (&qt)[9], int k0, T (&obs)[xk::OBS_DIM], T &reward,
+                           bool &done, bool &success, Lds lds) {
+    const ArmLane<T> C = arm_lane_consts<T>(G);
+    if (k0 == 0) xk::step_open(st, act, qt);
+    const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+#pragma unroll 1
+    for (int k = k0; k < xm::PNP_N_SUBSTEPS; k++) substep<T, Lds>(G, C, st, qt, dt, lds);
+    xk::step_close(cfg, st, obs, reward, done, success);
+}
+
 } // namespace xc

@@ -1373,6 +1373,57 @@ XARM_HD bool env_step_fast(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4]
     return !pad;
 }
 
+// ---- the STAGED step (xarm_step, xarm_hip.hip; as for Handover, xarm_handover_core.h lane_step_fast_range): the 15 substeps of a
+// step in stages.  step_open / step_close are the two ends of env_step above; a stage that begins at substep k0 > 0 continues the
+// step with the joint targets qt the opening stage left.
+template <typename T> XARM_HD void step_open(EnvState<T> &st, const T (&act)[4], T (&qt)[9]) {
+    st.steps += (T)1;
+    T a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = clampT(act[k], (T)-1, (T)1);
+    Frame<T> f = frame_identity<T>();
+#pragma unroll
+    for (int i = 0; i < 7; i++) fk_advance(f, i, st.q[i]);
+    const T sc = (T)(xm::PNP_MAX_VEL * xm::PNP_ACTION_DT);
+    const V3<T> target = mk<T>(clampT(f.o.x + a[0] * sc, (T)xm::PNP_POS_LOW[0], (T)xm::PNP_POS_HIGH[0]),
+                               clampT(f.o.y + a[1] * sc, (T)xm::PNP_POS_LOW[1], (T)xm::PNP_POS_HIGH[1]),
+                               clampT(f.o.z + a[2] * sc, (T)xm::PNP_POS_LOW[2], (T)xm::PNP_POS_HIGH[2]));
+    const T g = clampT(st.q[7] + a[3] * (T)(xm::PNP_ACTION_DT * xm::PNP_MAX_GRIPPER_VEL), (T)xm::PNP_GRIPPER_LOW, (T)xm::PNP_GRIPPER_HIGH);
+    ik_solve(st.q, target, qt);
+    qt[7] = qt[8] = g;
+    st.mug = st.touch;
+}
+template <typename T> XARM_HD void step_close(const EnvCfg &cfg, EnvState<T> &st, T (&obs)[OBS_DIM], T &reward, bool &done, bool &success) {
+    get_obs(st, obs);
+    const T dx = st.bp[0] - st.goal[0], dy = st.bp[1] - st.goal[1], dz = st.bp[2] - st.goal[2];
+    const T dist = xsqrt(dx * dx + dy * dy + dz * dz);
+    success = dist < (T)xm::PNP_DISTANCE_THRESHOLD;
+    reward = cfg.reward_type == 2 ? dense_reward<T>(st, obs, dist) : reward_of<T>(cfg.reward_type, dist);
+    done = success || ((int)st.steps == xm::PNP_MAX_EPISODE_STEPS);
+}
+// substeps [k0, k1) on the pad-free fast substep; false: a pad row was active in one of them (store nothing)
+template <typename T, typename Lds>
+XARM_HD bool env_step_fast_range(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (&qt)[9], int k0, int k1, T (&obs)[OBS_DIM], T &reward,
+                                 bool &done, bool &success, Lds lds) {
+    if (k0 == 0) step_open(st, act, qt);
+    const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+    bool pad = false;
+#pragma unroll 1
+    for (int k = k0; k < k1; k++) pad = substep<T, Lds, PnpScene, NoXchg, true>(st, qt, dt, lds) || pad;
+    if (k1 == xm::PNP_N_SUBSTEPS) step_close(cfg, st, obs, reward, done, success);
+    return !pad;
+}
+// substeps [k0, 15) on the full substep (the long-list fall-back of a staged hand-off)
+template <typename T, typename Lds>
+XARM_HD void env_step_from(const EnvCfg &cfg, EnvState<T> &st, const T (&act)[4], T (&qt)[9], int k0, T (&obs)[OBS_DIM], T &reward, bool &done,
+                           bool &success, Lds lds) {
+    if (k0 == 0) step_open(st, act, qt);
+    const T dt = (T)(xm::PNP_TIME_STEP / xm::PNP_N_SUBSTEPS);
+#pragma unroll 1
+    for (int k = k0; k < xm::PNP_N_SUBSTEPS; k++) substep<T, Lds>(st, qt, dt, lds);
+    step_close(cfg, st, obs, reward, done, success);
+}
+
 // Lazy auto-reset (opt-in, NOT the reference's VecEnv semantics): instead of running the reference's
 // PNP_RESET_TICKS + 1 reset ticks inside the step call in which an env finishes - six sequential ticks of latency for a
 // handful of envs while the rest of the GPU idles - a finished env spends its next six step calls on

@@ -240,6 +240,25 @@ __global__ __launch_bounds__(WG) void k_step_coop_list(KParams P, const float *_
                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
                                                        int *__restrict__ done_list, int *__restrict__ done_count,
                                                        const int *__restrict__ list, const int *__restrict__ count);
+// the staged PickAndPlace step (xarm_k_pnp.hip, xarm_k_pnp_coop.hip)
+__global__ __launch_bounds__(WG) void k_step_fast_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                        float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                        int *__restrict__ done_list, int *__restrict__ done_count,
+                                                        int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage);
+__global__ __launch_bounds__(WG) void k_step_from_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                        float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                        int *__restrict__ done_list, int *__restrict__ done_count,
+                                                        const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
+__global__ __launch_bounds__(WG) void k_step_coop_list_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                             float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                             uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                             int *__restrict__ done_list, int *__restrict__ done_count,
+                                                             const int *__restrict__ list, const int *__restrict__ count, HoStage stage);
 __global__ __launch_bounds__(WG) void k_substeps(KParams P, const float *__restrict__ qt_in, int n);
 __global__ void k_compact_mask(const uint8_t *__restrict__ mask, int64_t n, int *__restrict__ list, int *__restrict__ count);
 __global__ void k_get_state(KParams P, float *__restrict__ out);

@@ -261,6 +261,12 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
         h->ho_stages = handover1 && h->fast_pipeline ? XARM_HO_STAGES_DEFAULT : 1;
         ev = getenv("XARM_HO_STAGES");
         if (ev && *ev && handover1 && h->fast_pipeline) h->ho_stages = atoi(ev) < 1 ? 1 : (atoi(ev) > xarm_handle::MAX_ST ? xarm_handle::MAX_ST : atoi(ev));
+        // PickAndPlace: the same staging of the 15 substeps (XARM_PNP_STAGES; 1 = unstaged)
+        const bool pnp_pipe = cfg->env_kind == XARM_ENV_PICK_AND_PLACE && h->fast_pipeline;
+        if (pnp_pipe) h->ho_stages = XARM_PNP_STAGES_DEFAULT;
+        ev = getenv("XARM_PNP_STAGES");
+        if (ev && *ev && pnp_pipe) h->ho_stages = atoi(ev) < 1 ? 1 : (atoi(ev) > xarm_handle::MAX_ST ? xarm_handle::MAX_ST : atoi(ev));
+        static_assert(xm::HO_N_TICKS == xm::PNP_N_SUBSTEPS, "one stage table for both");
         for (int c = 0; c <= h->ho_stages; c++) h->ho_tick[c] = c * xm::HO_N_TICKS / h->ho_stages;
         // measurement hook: XARM_HO_STAGE_TICKS="3,9" = the interior stage boundaries (increasing, inside 1 .. 14)
         ev = getenv("XARM_HO_STAGE_TICKS");
@@ -297,7 +303,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
     h->done_count = h->counters; h->eject_count = h->counters + 1; h->class_hist = h->counters + 3;
     hipError_t e4 = hipMalloc(&h->mask_count, sizeof(int));
     if (e4 == hipSuccess && h->fast_pipeline) {
-        e4 = hipMalloc(&h->eject_list, sizeof(int) * stride * (handover1 ? h->ho_stages : 1));   // one list per stage
+        e4 = hipMalloc(&h->eject_list, sizeof(int) * stride * h->ho_stages);   // one list per stage
         if (e4 == hipSuccess) e4 = hipMalloc(&h->done_list_b, sizeof(int) * stride);
         const char *ev = getenv("XARM_RESET_OVERLAP");
         // (PickAndPlace only: Handover's reset is six single-substep ticks, 0.28 ms whether it runs beside the hand-off or after
@@ -309,7 +315,7 @@ int xarm_create(const xarm_config *cfg, xarm_handle **out) {
             h->reset_overlap = e4 == hipSuccess;
         }
     }
-    if (e4 == hipSuccess && h->fast_pipeline && handover1 && h->ho_stages > 1) {
+    if (e4 == hipSuccess && h->fast_pipeline && h->ho_stages > 1) {
         e4 = hipMalloc(&h->ho_qt, sizeof(float) * 18 * stride);
         if (e4 == hipSuccess) e4 = hipMalloc(&h->ho_flag, stride);
         if (e4 == hipSuccess) e4 = hipMemset(h->ho_flag, 0, stride);
@@ -518,6 +524,41 @@ int xarm_step(xarm_handle *h, const float *actions_dev, float *obs_dev, float *a
     else if (h->kp.num_envs <= (int64_t)h->coop_step_limit)
         k_step_coop<<<dim3((unsigned)((h->kp.num_envs + COOP_ENVS - 1) / COOP_ENVS)), dim3(WG), 0, st>>>(
             h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, h->done_list, cnt);
+    else if (h->fast_pipeline && h->ho_stages > 1) {
+        // STAGED PickAndPlace step (XARM_PNP_STAGES): as the staged Handover step above - fast stages on the caller's stream, each
+        // stage's hand-off on a side stream beside the next stage, the last one's on the caller's stream; with the reset overlap the
+        // episodes that ended on the fast path are reset on `side` after the last fast stage, those that ended in a hand-off after all of them
+        pipelined = true;
+        const int nst = h->ho_stages;
+        const int64_t cap = h->kp.num_envs < (int64_t)h->kp.eject_coop_cap ? h->kp.num_envs : (int64_t)h->kp.eject_coop_cap;
+        const unsigned cgrid = (unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS) < 1024u ? (unsigned)((cap + COOP_ENVS - 1) / COOP_ENVS) : 1024u;
+        int *list_b = overlap ? h->done_list_b : h->done_list, *cnt_b = overlap ? h->eject_count + 1 : cnt;
+        for (int c = 0; c < nst; c++) {
+            const HoStage sg{h->ho_tick[c], h->ho_tick[c + 1], h->ho_qt, h->ho_flag};
+            int *elist = h->eject_list + (int64_t)c * h->kp.stride, *ecnt = c == 0 ? h->eject_count : h->counters + 3 + c;
+            k_step_fast_stage<<<dim3(grid), dim3(WG), 0, st>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                               terminal_obs_dev, h->done_list, cnt, elist, ecnt, sg);
+            hipStream_t hs = st;
+            if (c + 1 < nst) {
+                hs = h->st_side[c];
+                HIPCHK(h, hipEventRecord(h->st_fork[c], st));
+                HIPCHK(h, hipStreamWaitEvent(hs, h->st_fork[c], 0));
+            } else if (overlap) {
+                HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+                launch_pnp_reset(h, h->done_list, cnt, obs_dev, ag_dev, dg_dev, h->side);
+                HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+            }
+            const HoStage rest{sg.tick0, xm::PNP_N_SUBSTEPS, h->ho_qt, h->ho_flag};
+            k_step_coop_list_stage<<<dim3(cgrid), dim3(WG), 0, hs>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                     terminal_obs_dev, list_b, cnt_b, elist, ecnt, rest);
+            if (h->kp.num_envs > cap)
+                k_step_from_stage<<<dim3(grid), dim3(WG), 0, hs>>>(h->kp, actions_dev, obs_dev, ag_dev, dg_dev, reward_dev, done_dev, success_dev,
+                                                                   terminal_obs_dev, list_b, cnt_b, elist, ecnt, rest);
+            if (c + 1 < nst) HIPCHK(h, hipEventRecord(h->st_join[c], hs));
+        }
+        for (int c = 0; c + 1 < nst; c++) HIPCHK(h, hipStreamWaitEvent(st, h->st_join[c], 0));
+    }
     else if (h->fast_pipeline) {
         // every env on the pad-free fast step; the ones with an active finger-pad row are handed off, untouched, to the
         // cooperative kernel (lists of at most eject_coop_cap envs) or to k_step (longer lists) - both launched, the one
@@ -695,7 +736,7 @@ int xarm_stage_info(const xarm_handle *h, int32_t *stages, int32_t *ticks) {
     *stages = staged ? h->ho_stages : 1;
     for (int c = 0; c <= XARM_HO_MAX_STAGES; c++) ticks[c] = 0;
     if (staged) for (int c = 0; c <= h->ho_stages; c++) ticks[c] = h->ho_tick[c];
-    else if (h->cfg.env_kind == XARM_ENV_HANDOVER) ticks[1] = xm::HO_N_TICKS;
+    else if (h->cfg.env_kind == XARM_ENV_HANDOVER || h->cfg.env_kind == XARM_ENV_PICK_AND_PLACE) ticks[1] = xm::HO_N_TICKS;   // (15 ticks / 15 substeps)
     return XARM_OK;
 }
 int xarm_pipeline_info(const xarm_handle *h, int32_t *fast_pipeline, int32_t *reset_overlap, int32_t *eject_coop_cap,

@@ -90,6 +90,87 @@ __global__ __launch_bounds__(WG) void k_step_fast(KParams P, const float *__rest
     }
 }
 
+// ---- the STAGED step (XARM_PNP_STAGES > 1; xarm_step): stage kernels beside the unstaged ones above, which stay as they are.
+// qt[9][stride]: the joint targets the opening stage computed; flag[e] != 0: env e was handed off in an earlier stage of this call.
+__device__ __forceinline__ void pnp_finish(const KParams &P, int64_t e, const xk::EnvState<float> &s, const float (&obs)[xk::OBS_DIM], float reward,
+                                           bool done, bool success, float *obs_out, float *ag_out, float *dg_out, float *rew_out, uint8_t *done_out,
+                                           uint8_t *succ_out, float *term_obs, int *done_list, int *done_count) {
+    write_obs(obs, s, e, obs_out, ag_out, dg_out);
+    rew_out[e] = reward;
+    done_out[e] = done ? 1 : 0;
+    succ_out[e] = success ? 1 : 0;
+    if (done && P.auto_reset) {
+        if (term_obs) {
+            float4 *o = reinterpret_cast<float4 *>(term_obs + e * xk::OBS_DIM);
+#pragma unroll
+            for (int k = 0; k < xk::OBS_DIM / 4; k++) o[k] = make_float4(obs[4 * k], obs[4 * k + 1], obs[4 * k + 2], obs[4 * k + 3]);
+        }
+        const int pos = atomicAdd(done_count, 1);
+        done_list[pos] = (int)e;
+    }
+}
+// substeps [stage.tick0, stage.tick1) of the step on the pad-free fast substep; an env with an active pad row in them stores nothing,
+// is flagged and appended to eject_list (its hand-off re-runs the substeps from stage.tick0 on)
+__global__ __launch_bounds__(WG) void k_step_fast_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                        float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                        int *__restrict__ done_list, int *__restrict__ done_count,
+                                                        int *__restrict__ eject_list, int *__restrict__ eject_count, HoStage stage) {
+    __shared__ float smem[FAST_LDS_FLOATS * WG];
+    const int64_t e_in = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e_in >= P.num_envs) return;
+    if (stage.tick0 > 0 && stage.flag[e_in]) return;
+    FastLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e_in, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xk::OBS_DIM], reward, qt[9];
+    bool done, success;
+    if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, 0, qt);
+    const bool ok = xk::env_step_fast_range<float, FastLds>(P.cfg, s, act, qt, stage.tick0, stage.tick1, obs, reward, done, success, lds);
+    const int64_t e = late_index(e_in);
+    if (!ok) {
+        const int pos = atomicAdd(eject_count, 1);
+        eject_list[pos] = (int)e;
+        stage.flag[e] = 1;
+        return;
+    }
+    store_state(P, e, s);
+    if (stage.tick1 < xm::PNP_N_SUBSTEPS) {
+        if (stage.tick0 == 0) { ho_store_qt(P, stage, e, 0, qt); stage.flag[e] = 0; }
+        return;
+    }
+    pnp_finish(P, e, s, obs, reward, done, success, obs_out, ag_out, dg_out, rew_out, done_out, succ_out, term_obs, done_list, done_count);
+}
+// the long-list fall-back of a staged hand-off: substeps [stage.tick0, 15) of the envs list[0 .. *count) on the full one-env-per-lane substep
+__global__ __launch_bounds__(WG) void k_step_from_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                        float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                        uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                        int *__restrict__ done_list, int *__restrict__ done_count,
+                                                        const int *__restrict__ list, const int *__restrict__ count, HoStage stage) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t i_in = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t n = (int64_t)*count;
+    if (n <= P.eject_coop_cap) return;     // k_step_coop_list_stage's range
+    if (i_in >= n) return;
+    const int64_t e_in = (int64_t)list[i_in];
+    DevLds lds{smem + threadIdx.x};
+    xk::EnvState<float> s;
+    load_state(P, e_in, s);
+    const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    float obs[xk::OBS_DIM], reward, qt[9];
+    bool done, success;
+    if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, 0, qt);
+    xk::env_step_from<float, DevLds>(P.cfg, s, act, qt, stage.tick0, obs, reward, done, success, lds);
+    const int64_t e = late_index(e_in);
+    store_state(P, e, s);
+    pnp_finish(P, e, s, obs, reward, done, success, obs_out, ag_out, dg_out, rew_out, done_out, succ_out, term_obs, done_list, done_count);
+}
+
 // lazy auto-reset (xk::env_step_lazy): a finished env runs its reset ticks in its next six step calls; no reset launch,
 // no done list.  done_out carries the phase: 0 ordinary step, 1 the episode ended in this call, 2 reset tick.
 __global__ __launch_bounds__(WG) void k_step_lazy(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,

@@ -118,4 +118,49 @@ __global__ __launch_bounds__(WG) void k_step_coop_list(KParams P, const float *_
     }
 }
 
+// the hand-off of a staged step: substeps [stage.tick0, 15) of the envs list[0 .. *count) on the cooperative core
+__global__ __launch_bounds__(WG) void k_step_coop_list_stage(KParams P, const float *__restrict__ actions, float *__restrict__ obs_out,
+                                                             float *__restrict__ ag_out, float *__restrict__ dg_out,
+                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                             uint8_t *__restrict__ succ_out, float *__restrict__ term_obs,
+                                                             int *__restrict__ done_list, int *__restrict__ done_count,
+                                                             const int *__restrict__ list, const int *__restrict__ count, HoStage stage) {
+    __shared__ float smem[xk::LDS_FLOATS * WG];
+    const int64_t n = (int64_t)*count;
+    if (n > P.eject_coop_cap) return;
+    const xc::Grp G{(int)(threadIdx.x & (xc::GL - 1))};
+    DevLds lds{smem + threadIdx.x};
+#pragma unroll 1
+    for (int64_t i0 = (int64_t)blockIdx.x * COOP_ENVS; i0 < n; i0 += (int64_t)gridDim.x * COOP_ENVS) {
+        const int64_t i_raw = i0 + threadIdx.x / xc::GL;
+        const bool live = i_raw < n;
+        const int64_t e_in = (int64_t)list[live ? i_raw : n - 1];
+        xk::EnvState<float> s;
+        load_state(P, e_in, s);
+        const float4 a4 = reinterpret_cast<const float4 *>(actions)[e_in];
+        const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+        float obs[xk::OBS_DIM], reward, qt[9];
+        bool done, success;
+        if (stage.tick0 > 0) ho_load_qt(P, stage, e_in, 0, qt);
+        xc::env_step_from<float, DevLds>(G, P.cfg, s, act, qt, stage.tick0, obs, reward, done, success, lds);
+        if (live && G.l == 0) {
+            const int64_t e = late_index(e_in);
+            store_state(P, e, s);
+            write_obs(obs, s, e, obs_out, ag_out, dg_out);
+            rew_out[e] = reward;
+            done_out[e] = done ? 1 : 0;
+            succ_out[e] = success ? 1 : 0;
+            if (done && P.auto_reset) {
+                if (term_obs) {
+                    float4 *o = reinterpret_cast<float4 *>(term_obs + e * xk::OBS_DIM);
+#pragma unroll
+                    for (int k = 0; k < xk::OBS_DIM / 4; k++) o[k] = make_float4(obs[4 * k], obs[4 * k + 1], obs[4 * k + 2], obs[4 * k + 3]);
+                }
+                const int pos = atomicAdd(done_count, 1);
+                done_list[pos] = (int)e;
+            }
+        }
+    }
+}
+
 } // namespace xd

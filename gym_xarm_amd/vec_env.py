@@ -289,8 +289,9 @@ class XarmPickAndPlaceVecEnv:
         return dict(fast_pipeline=bool(v[0].value), reset_overlap=bool(v[1].value), eject_coop_cap=v[2].value, solver_iterations=v[3].value)
 
     def stage_info(self):
-        """the staged Handover step (include/xarm_hip.h xarm_stage_info): the first tick of each fast stage and, last, the ticks of a
-        step - [0, 5, 10, 15] by default above 2 048 envs, [0, 15] unstaged, [0, 0] for the other env kinds"""
+        """the staged step of Handover (one stick) and PickAndPlace (include/xarm_hip.h xarm_stage_info): the first tick / substep of each
+        fast stage and, last, their number per step - [0, 5, 10, 15] by default for a pipelined handle, [0, 15] unstaged or small, [0, 0] for
+        the other env kinds"""
         n, t = C.c_int32(0), (C.c_int32 * 6)()
         _native.check(self._L, self._h, self._L.xarm_stage_info(self._h, C.byref(n), t), "xarm_stage_info")
         return [int(t[k]) for k in range(n.value + 1)]

@@ -122,6 +122,9 @@ typedef struct xarm_config {
  * caller's stream ends.  Which kernel runs which tick of an env is a function of that env's own state and of the handle's
  * configuration, never of its neighbours. */
 #define XARM_HO_STAGES_DEFAULT 3
+/* The pipelined PickAndPlace step (batches above step_coop_limit) is staged the same way over its 15 substeps: XARM_PNP_STAGES_DEFAULT
+ * fast launches (env XARM_PNP_STAGES = 1 .. 5 at xarm_create; 1 = one fast launch and one hand-off, round 3's pipeline). */
+#define XARM_PNP_STAGES_DEFAULT 3
 /* test hook: XARM_HO_FORCE_COUPLED=1 at xarm_create sends every substep of the cooperative Handover step and reset through the
  * coupled (both-arms) sweep - same bits by construction (tests/test_handover_coop.py) */
 

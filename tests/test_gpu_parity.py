@@ -401,6 +401,56 @@ def test_overlapped_reset_changes_nothing_but_the_time(gx, monkeypatch):
     assert int(on[:, :, 32].sum()) > 6 * 300          # done flags: the resets were really exercised
 
 
+def test_staged_pipeline_against_the_unstaged_one(gx, monkeypatch):
+    """The pipelined PickAndPlace step runs its fast kernel in three stages of five substeps (XARM_PNP_STAGES_DEFAULT), each stage's hand-off
+    re-running the substeps from that stage's first one on the cooperative kernel beside the next stage - against XARM_PNP_STAGES=1 (one fast
+    launch, one hand-off: round 3's pipeline) from identical states: an env that finishes on the fast path or is handed off in the first
+    stage runs the same code over the same substeps - the same bits; an env whose pads come alive later has its first substeps on the
+    lane core instead of the cooperative one - float32-close.  Run to run the staged step is bitwise reproducible (three streams), with
+    auto-reset as without."""
+    E = 16384
+    staged = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=41, auto_reset=False)
+    monkeypatch.setenv("XARM_PNP_STAGES", "1")
+    plain = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=41, auto_reset=False)
+    monkeypatch.delenv("XARM_PNP_STAGES")
+    assert staged.stage_info() == [0, 5, 10, 15] and plain.stage_info() == [0, 15]
+    staged.reset()
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    n_same = n_late = n_handed = 0
+    for t in range(12):
+        a = torch.rand(E, 4, device="cuda", generator=gen) * 2 - 1
+        st0 = staged.get_state().clone()
+        plain.set_state(st0)
+        obs, rew, done, _ = staged.step(a)
+        ref, handed = staged.get_state().clone(), staged.debug_counts()[1]
+        pobs, prew, pdone, _ = plain.step(a)
+        assert abs(plain.debug_counts()[1] - handed) <= 0.02 * handed + 2          # the same envs are handed off (but for borderline pads)
+        same = (ref == plain.get_state()).all(dim=1)
+        d = (ref - plain.get_state())[:, :31].abs().max(dim=1).values
+        assert float((d < 1e-3).float().mean()) > 0.995, (t, float(d.max()), float((d < 1e-3).float().mean()))
+        assert torch.equal(rew[same], prew[same]) and torch.equal(done[same], pdone[same]) and torch.equal(obs["observation"][same], pobs["observation"][same])
+        n_same += int(same.sum()); n_late += int((~same).sum()); n_handed += handed
+        staged.set_state(st0)
+        staged.step(a)
+        assert torch.equal(staged.get_state(), ref)                                  # run to run
+    assert n_handed > 12 * E // 100 and 0 < n_late < n_handed and n_same > 0.97 * 12 * E, (n_same, n_late, n_handed)
+    staged.close()
+    plain.close()
+    env = gx.make("XarmPDPickAndPlace-v0", num_envs=E, seed=42)                      # auto-reset: two runs, the same bits
+    outs = []
+    env.reset()
+    s0 = env.get_state().clone()
+    s0[:, 52] = (torch.arange(E, device="cuda") * 7919 % 50).float()                 # episode phases spread: ~330 resets per call
+    for rep in range(2):
+        env.set_state(s0)
+        g2 = torch.Generator(device="cuda").manual_seed(5)
+        for t in range(6):
+            env.step(torch.rand(E, 4, device="cuda", generator=g2) * 2 - 1)
+        outs.append(env.get_state().clone())
+    assert torch.equal(outs[0], outs[1])
+    env.close()
+
+
 def test_fast_pipeline_against_the_plain_step_kernel(gx, monkeypatch):
     """What a large PickAndPlace batch steps on by default - k_step_fast (the pad-free substep) with the hand-off of the
     envs that have an active finger-pad row to k_step_coop_list - against the plain k_step.  The fast substep is the plain

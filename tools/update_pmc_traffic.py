@@ -10,11 +10,11 @@ import sys
 
 # candidates per role, the first one present in the summary with counters wins (the fast pipeline's first kernel, the plain
 # kernel when the pipeline is off, the cooperative family at small batch sizes)
-STEP_KERNEL = {"pnp": ["k_step_fast", "k_step", "k_step_coop"], "reach": ["k_reach_step", "k_reach_step_coop"],
+STEP_KERNEL = {"pnp": ["k_step_fast_stage", "k_step_fast", "k_step", "k_step_coop"], "reach": ["k_reach_step", "k_reach_step_coop"],
                "handover": ["k_ho_step_fast", "k_ho_step"], "stack": ["k_st_step"], "handover2": ["k_ho2_step"]}
 RESET_KERNEL = {"pnp": ["k_reset_coop", "k_reset"], "reach": ["k_reach_reset", "k_reach_reset_coop"],
                 "handover": ["k_ho_reset_coop", "k_ho_reset"], "stack": ["k_st_reset"], "handover2": ["k_ho2_reset"]}
-HANDOFF_KERNEL = {"pnp": ["k_step_coop_list"], "handover": ["k_ho_step_coop_list"]}
+HANDOFF_KERNEL = {"pnp": ["k_step_coop_list_stage", "k_step_coop_list"], "handover": ["k_ho_step_coop_list"]}
 
 
 def main():
